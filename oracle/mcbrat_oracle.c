@@ -1,0 +1,886 @@
+/*
+ * mcbrat_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * Plain-C restatement of MCBRaT3D's photon-tracing path.  Every function cites
+ * the reference file:line it follows (paths relative to /root/reference).
+ * Arithmetic kinds follow the Fortran: `real` = float, `real(8)` = double,
+ * default integer = int32.  Build with -O2 -ffp-contract=off and without
+ * -ffast-math so that float/double expression order is what is written here.
+ *
+ * Who may use this: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline.
+ */
+#include "mcbrat_oracle.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* Fortran intrinsics                                                        */
+/* ------------------------------------------------------------------------ */
+static double spacing_d(double x) { /* SPACING(real(8)) */
+  if (x == 0.0) return DBL_MIN;
+  int e;
+  frexp(fabs(x), &e);
+  double s = ldexp(1.0, e - 53);
+  return s < DBL_MIN ? DBL_MIN : s;
+}
+static float spacing_f(float x) { /* SPACING(real) */
+  if (x == 0.0f) return FLT_MIN;
+  int e;
+  frexpf(fabsf(x), &e);
+  float s = ldexpf(1.0f, e - 24);
+  return s < FLT_MIN ? FLT_MIN : s;
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/RandomNumbersForMC.f95                                                */
+/* ------------------------------------------------------------------------ */
+#define MT_N 624
+#define MT_M 397
+
+void orc_mt_init_scalar(orc_rng *r, int32_t seed) { /* :171-187 */
+  r->mode = 0;
+  r->mt[0] = (uint32_t)seed;
+  for (int i = 1; i < MT_N; i++)
+    r->mt[i] = 1812433253u * (r->mt[i - 1] ^ (r->mt[i - 1] >> 30)) + (uint32_t)i;
+  r->mti = MT_N;
+  r->ndraws = 0;
+}
+
+void orc_mt_init_vector(orc_rng *r, const int32_t *seed, int n) { /* :189-241 */
+  orc_mt_init_scalar(r, 19650218);
+  int nWraps = 0;
+  int nFirstLoop = MT_N > n ? MT_N : n;
+  uint32_t *s = r->mt;
+  for (int k = 1; k <= nFirstLoop; k++) {
+    int i = (k + nWraps) % MT_N;
+    int j = (k - 1) % n;
+    if (i == 0) { /* :202-209: wrap, then the update lands on element 1 */
+      s[0] = s[MT_N - 1];
+      s[1] = (s[1] ^ ((s[0] ^ (s[0] >> 30)) * 1664525u)) + (uint32_t)seed[j] + (uint32_t)j;
+      nWraps++;
+    } else {
+      s[i] = (s[i] ^ ((s[i - 1] ^ (s[i - 1] >> 30)) * 1664525u)) + (uint32_t)seed[j] + (uint32_t)j;
+    }
+  }
+  for (int i = nFirstLoop % MT_N + nWraps + 1; i <= MT_N - 1; i++) /* :222-227 */
+    s[i] = (s[i] ^ ((s[i - 1] ^ (s[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+  s[0] = s[MT_N - 1];
+  for (int i = 1; i <= nFirstLoop % MT_N + nWraps; i++) /* :231-236 */
+    s[i] = (s[i] ^ ((s[i - 1] ^ (s[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+  s[0] = 0x80000000u; /* :238 UMASK */
+  r->mti = MT_N;
+}
+
+static void mt_next_state(orc_rng *r) { /* :118-154 */
+  uint32_t *s = r->mt;
+  int k;
+#define MT_TWIST(u, v) (((((u) & 0x80000000u) | ((v) & 0x7fffffffu)) >> 1) ^ (((v) & 1u) ? 0x9908b0dfu : 0u))
+  for (k = 0; k < MT_N - MT_M; k++) s[k] = s[k + MT_M] ^ MT_TWIST(s[k], s[k + 1]);
+  for (; k < MT_N - 1; k++) s[k] = s[k + MT_M - MT_N] ^ MT_TWIST(s[k], s[k + 1]);
+  s[MT_N - 1] = s[MT_M - 1] ^ MT_TWIST(s[MT_N - 1], s[0]);
+  r->mti = 0;
+}
+
+uint32_t orc_mt_next_u32(orc_rng *r) { /* getRandomInt :245-260, temper :156-167 */
+  if (r->mti >= MT_N) mt_next_state(r);
+  uint32_t y = r->mt[r->mti++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+/* Philox4x32-10 (Salmon et al., SC'11): the counter-based generator the
+ * north_star substitutes for the stateful MT stream. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int i = 0; i < 10; i++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void orc_philox_init(orc_rng *r, uint64_t seed, uint64_t firstPhoton) {
+  memset(r, 0, sizeof(*r));
+  r->mode = 1;
+  r->seed = seed;
+  r->firstPhoton = firstPhoton;
+}
+
+static void philox_start_photon(orc_rng *r, uint64_t photon) {
+  r->photon = photon;
+  r->draw = 0;
+}
+
+static uint32_t rng_u32(orc_rng *r) {
+  r->ndraws++;
+  if (r->mode == 0) return orc_mt_next_u32(r);
+  if ((r->draw & 3u) == 0) {
+    uint32_t ctr[4] = {r->draw >> 2, 0u, (uint32_t)r->photon, (uint32_t)(r->photon >> 32)};
+    uint32_t key[2] = {(uint32_t)r->seed, (uint32_t)(r->seed >> 32)};
+    orc_philox4x32_10(ctr, key, r->buf);
+  }
+  return r->buf[r->draw++ & 3u];
+}
+
+/* getRandomDouble / getRandomReal :277-301: u32/(2^32-1) in double, then to
+ * float; the closed interval [0,1] (both ends attainable).  The Philox mode
+ * multiplies by the reciprocal (what the HIP kernel does) instead of dividing. */
+float orc_random_real(orc_rng *r) {
+  uint32_t u = rng_u32(r);
+  if (r->mode == 0) return (float)((double)u / 4294967295.0);
+  return (float)((double)u * (1.0 / 4294967295.0));
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/numericUtilities.f95                                                  */
+/* ------------------------------------------------------------------------ */
+void orc_legendre(int maxL, int nmu, const float *mus, float *out) { /* :187-205 */
+  int ld = maxL + 1;
+  for (int j = 0; j < nmu; j++) {
+    float *P = out + (size_t)j * ld;
+    P[0] = 1.0f;
+    if (maxL >= 1) P[1] = mus[j];
+    for (int l = 1; l <= maxL - 1; l++)
+      P[l + 1] = (((float)(2 * l + 1) * mus[j]) * P[l] - (float)l * P[l - 1]) / (float)(l + 1);
+  }
+}
+
+void orc_lobatto(int n, float *mus, float *weights) { /* :27-114 */
+  const float relativeAccuracy = 3.0f;
+  const int maxIterations = 25;
+  float pi = acosf(-1.0f);
+  int nTerms = n;
+  int midPoint = (nTerms + 1) / 2;
+  int m = midPoint - 1;
+  float *trial = (float *)calloc(m > 0 ? m : 1, sizeof(float));
+  float *last = (float *)calloc(m > 0 ? m : 1, sizeof(float));
+  float *der = (float *)calloc(m > 0 ? m : 1, sizeof(float));
+  float *sec = (float *)calloc(m > 0 ? m : 1, sizeof(float));
+  int ld = nTerms; /* legendreP(0:nTerms-1, m) */
+  float *P = (float *)calloc((size_t)ld * (m > 0 ? m : 1), sizeof(float));
+  float c1 = (nTerms % 2 == 1) ? 1.0f : 0.5f;
+  float denom = ((float)nTerms - 1.0f) + 0.5f;
+  float nm1 = (float)(nTerms - 1);
+  float nn1 = (float)(nTerms * (nTerms - 1));
+  for (int i = 1; i <= m; i++) trial[i - 1] = sinf((pi * ((float)i - c1)) / denom);
+
+  orc_legendre(nTerms - 1, m, trial, P);
+  for (int j = 0; j < m; j++) { /* first Newton step :59-69 */
+    const float *Pj = P + (size_t)j * ld;
+    der[j] = (nm1 * (trial[j] * Pj[nTerms - 1] - Pj[nTerms - 2])) / (trial[j] * trial[j] - 1.0f);
+    sec[j] = ((2.0f * trial[j]) * der[j] - (nn1 * Pj[nTerms - 1])) / (1.0f - trial[j] * trial[j]);
+    last[j] = trial[j];
+    trial[j] = trial[j] - der[j] / sec[j];
+  }
+  int it = 0;
+  for (;;) { /* :73-95 */
+    int allDone = 1;
+    for (int j = 0; j < m; j++)
+      if (!(fabsf(trial[j] - last[j]) <= relativeAccuracy * spacing_f(trial[j]))) allDone = 0;
+    if (allDone) break;
+    orc_legendre(nTerms - 1, m, trial, P);
+    for (int j = 0; j < m; j++) {
+      if (fabsf(trial[j] - last[j]) > relativeAccuracy * spacing_f(trial[j])) {
+        const float *Pj = P + (size_t)j * ld;
+        der[j] = (nm1 * (trial[j] * Pj[nTerms - 1] - Pj[nTerms - 2])) / (trial[j] * trial[j] - 1.0f);
+        sec[j] = ((2.0f * trial[j]) * der[j] - (nn1 * Pj[nTerms - 1])) / (1.0f - trial[j] * trial[j]);
+        last[j] = trial[j];
+        trial[j] = trial[j] - der[j] / sec[j];
+      }
+    }
+    it++;
+    if (it > maxIterations) break;
+  }
+  /* :98-111, 1-based m(i) = mus[i-1] */
+  mus[0] = -1.0f;
+  weights[0] = 2.0f / nn1;
+  for (int j = 0; j < m; j++) { /* mus(midPoint:2:-1) = -trialMus(:) */
+    const float *Pj = P + (size_t)j * ld;
+    mus[midPoint - 1 - j] = -trial[j];
+    weights[midPoint - 1 - j] = 2.0f / (nn1 * (Pj[nTerms - 1] * Pj[nTerms - 1]));
+  }
+  if (nTerms % 2 == 0) {
+    for (int k = 0; k < midPoint; k++) { /* mus(mid+1:n) = -mus(mid:1:-1) */
+      mus[midPoint + k] = -mus[midPoint - 1 - k];
+      weights[midPoint + k] = weights[midPoint - 1 - k];
+    }
+  } else {
+    float *tm = (float *)malloc(sizeof(float) * midPoint), *tw = (float *)malloc(sizeof(float) * midPoint);
+    for (int k = 0; k < midPoint; k++) { tm[k] = -mus[midPoint - 1 - k]; tw[k] = weights[midPoint - 1 - k]; }
+    for (int k = 0; k < midPoint; k++) { mus[midPoint - 1 + k] = tm[k]; weights[midPoint - 1 + k] = tw[k]; }
+    free(tm); free(tw);
+  }
+  free(trial); free(last); free(der); free(sec); free(P);
+}
+
+/* findIndex family.  Tables are 1-based in the reference: t(i) == t[i-1]. */
+#define FIND_INDEX_BODY(T1)                                                         \
+  int lowerBound, upperBound, midPoint, increment;                                  \
+  if (firstGuess > 0) {                                                             \
+    lowerBound = firstGuess; increment = 1;                                         \
+    for (;;) {                                                                      \
+      upperBound = lowerBound + increment < n ? lowerBound + increment : n;         \
+      if (lowerBound == n || (T1(lowerBound) <= v && T1(upperBound) > v)) break;    \
+      if (T1(lowerBound) > v) {                                                     \
+        upperBound = lowerBound;                                                    \
+        lowerBound = upperBound - increment > 1 ? upperBound - increment : 1;       \
+      } else lowerBound = upperBound;                                               \
+      increment *= 2;                                                               \
+    }                                                                               \
+  } else { lowerBound = 0; upperBound = n; }                                        \
+  for (;;) {                                                                        \
+    if (lowerBound == n || upperBound <= lowerBound + 1) break;                     \
+    midPoint = (lowerBound + upperBound) / 2;                                       \
+    if (v >= T1(midPoint)) lowerBound = midPoint; else upperBound = midPoint;       \
+  }                                                                                 \
+  return lowerBound;
+
+int orc_find_index_real(float v, const float *t, int n, int firstGuess) { /* :417-470 */
+#define T1(i) (t[(i)-1])
+  FIND_INDEX_BODY(T1)
+#undef T1
+}
+int orc_find_index_double(double v, const double *t, int n, int firstGuess) { /* :207-260 */
+#define T1(i) (t[(i)-1])
+  FIND_INDEX_BODY(T1)
+#undef T1
+}
+int orc_find_index_mixed(float vf, const double *t, int n, int firstGuess) { /* :262-315 */
+  double v = (double)vf;
+#define T1(i) (t[(i)-1])
+  FIND_INDEX_BODY(T1)
+#undef T1
+}
+int orc_find_cdf_index(float vf, const double *t, int n) { /* :317-348 */
+  double v = (double)vf;
+  int lowerBound = 0, upperBound = n, midPoint;
+  for (;;) {
+    if (lowerBound == n || upperBound <= lowerBound + 1) break;
+    midPoint = (lowerBound + upperBound) / 2;
+    if (v > t[midPoint - 1]) lowerBound = midPoint; else upperBound = midPoint;
+  }
+  return upperBound;
+}
+/* strided variant for colWeights / voxelWeights slices of the running CDF */
+static int find_cdf_index_strided(float vf, const double *t, int n, int64_t stride) {
+  double v = (double)vf;
+  int lowerBound = 0, upperBound = n, midPoint;
+  for (;;) {
+    if (lowerBound == n || upperBound <= lowerBound + 1) break;
+    midPoint = (lowerBound + upperBound) / 2;
+    if (v > t[(int64_t)(midPoint - 1) * stride]) lowerBound = midPoint; else upperBound = midPoint;
+  }
+  return upperBound;
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/scatteringPhaseFunctions.f95                                          */
+/* ------------------------------------------------------------------------ */
+void orc_phase_values_legendre(int ncoef, const float *coef, int nang, const float *angles,
+                               float *values) { /* getPhaseFunctionValues_one :480-498 */
+  int maxL = ncoef;
+  if (maxL == 0) { for (int j = 0; j < nang; j++) values[j] = 0.5f; return; }
+  float *cosA = (float *)malloc(sizeof(float) * nang);
+  float *P = (float *)malloc(sizeof(float) * (size_t)(maxL + 1) * nang);
+  float *v = (float *)malloc(sizeof(float) * (maxL + 1));
+  for (int j = 0; j < nang; j++) cosA[j] = cosf(angles[j]);
+  orc_legendre(maxL, nang, cosA, P);
+  for (int l = 0; l <= maxL; l++) v[l] = (l == 0 ? 1.0f : coef[l - 1]) * (float)(2 * l + 1);
+  for (int j = 0; j < nang; j++) { /* matmul(vector, matrix): sum over l ascending */
+    float s = 0.0f;
+    const float *Pj = P + (size_t)j * (maxL + 1);
+    for (int l = 0; l <= maxL; l++) s += v[l] * Pj[l];
+    values[j] = s;
+  }
+  free(cosA); free(P); free(v);
+}
+
+void orc_normalize_phase_function(int n, const float *angles, const float *vin, float *vout) { /* :1520-1536 */
+  float dot = 0.0f;
+  for (int i = 0; i < n - 1; i++)
+    dot += (cosf(angles[i + 1]) - cosf(angles[i])) * (0.5f * (vin[i + 1] + vin[i]));
+  for (int i = 0; i < n; i++) vout[i] = (-vin[i] * 2.0f) / dot;
+}
+
+void orc_phase_values_tabulated(int nst, const float *stA, const float *stV, int nang,
+                                const float *angles, float *values) { /* :500-527 */
+  for (int l = 0; l < nang; l++) {
+    int ti = orc_find_index_real(angles[l], stA, nst, 0);
+    int tp = ti + 1;
+    float dMu;
+    if (ti < nst) dMu = cosf(stA[tp - 1]) - cosf(stA[ti - 1]);
+    else { dMu = FLT_MAX; tp = ti; }
+    float w = 1.0f - (cosf(angles[l]) - cosf(stA[ti - 1])) / dMu;
+    values[l] = w * stV[ti - 1] + (1.0f - w) * stV[tp - 1];
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/inversePhaseFunctions.f95:66-174                                      */
+/* ------------------------------------------------------------------------ */
+static int inverse_from_cdf_inputs(int nAngles, const float *mus, const float *values, int nSteps,
+                                   float *table) { /* :114-169 */
+  float *cdf = (float *)malloc(sizeof(float) * nAngles);
+  int *ind = (int *)malloc(sizeof(int) * nSteps);
+  cdf[0] = 0.0f;
+  for (int i = 1; i < nAngles; i++)
+    cdf[i] = cdf[i - 1] + ((mus[i] - mus[i - 1]) * 0.5f) * (values[i] + values[i - 1]);
+  float tot = cdf[nAngles - 1];
+  for (int i = 0; i < nAngles; i++) cdf[i] = cdf[i] / tot;
+  ind[0] = orc_find_index_real(0.0f, cdf, nAngles, 0);
+  for (int i = 2; i <= nSteps; i++) {
+    float p = (float)(i - 1) / (float)(nSteps - 1);
+    ind[i - 1] = orc_find_index_real(p, cdf, nAngles, ind[i - 2]);
+  }
+  for (int i = 1; i <= nSteps - 1; i++) {
+    float p = (float)(i - 1) / (float)(nSteps - 1);
+    int k = ind[i - 1]; /* 1-based */
+    if (k >= nAngles) k = nAngles - 1; /* guard: the reference would index past the table */
+    float c0 = cdf[k - 1], c1 = cdf[k], m0 = mus[k - 1], m1 = mus[k], v0 = values[k - 1], v1 = values[k];
+    if (c1 - c0 <= spacing_f(c0)) {
+      table[i - 1] = acosf(m0);
+    } else if (fabsf(v0 - v1) <= spacing_f(v0)) {
+      table[i - 1] = acosf(m0 + ((m1 - m0) * (p - c0)) / (c1 - c0));
+    } else {
+      float root = sqrtf(((c1 - p) * (v0 * v0) + (p - c0) * (v1 * v1)) / (c1 - c0));
+      table[i - 1] = acosf(m0 + ((m1 - m0) / (v0 - v1)) * (v0 - root));
+    }
+  }
+  table[nSteps - 1] = 0.0f;
+  free(cdf); free(ind);
+  return 0;
+}
+
+int orc_inverse_table_legendre(int ncoef, const float *coef, int nSteps, float *table) {
+  int nAngles = ncoef > 2 ? ncoef : 2; /* :107 */
+  float *mus = (float *)malloc(sizeof(float) * nAngles);
+  float *wts = (float *)malloc(sizeof(float) * nAngles);
+  float *ang = (float *)malloc(sizeof(float) * nAngles);
+  float *val = (float *)malloc(sizeof(float) * nAngles);
+  float *valr = (float *)malloc(sizeof(float) * nAngles);
+  orc_lobatto(nAngles, mus, wts); /* :110 */
+  for (int i = 0; i < nAngles; i++) ang[i] = acosf(mus[nAngles - 1 - i]); /* :111 */
+  orc_phase_values_legendre(ncoef, coef, nAngles, ang, val);
+  for (int i = 0; i < nAngles; i++) valr[i] = val[nAngles - 1 - i]; /* :112 */
+  int rc = inverse_from_cdf_inputs(nAngles, mus, valr, nSteps, table);
+  free(mus); free(wts); free(ang); free(val); free(valr);
+  return rc;
+}
+
+int orc_inverse_table_tabulated(int nAngles, const float *angles, const float *values, int nSteps,
+                                float *table) { /* :88-98; values are the (already normalised) stored ones */
+  float *mus = (float *)malloc(sizeof(float) * nAngles);
+  float *val = (float *)malloc(sizeof(float) * nAngles);
+  float *valr = (float *)malloc(sizeof(float) * nAngles);
+  orc_phase_values_tabulated(nAngles, angles, values, nAngles, angles, val); /* :97 */
+  for (int i = 0; i < nAngles; i++) { mus[i] = cosf(angles[nAngles - 1 - i]); valr[i] = val[nAngles - 1 - i]; }
+  int rc = inverse_from_cdf_inputs(nAngles, mus, valr, nSteps, table);
+  free(mus); free(val); free(valr);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/opticalProperties.f95:1656-1815 accumulateExtinctionAlongPath         */
+/* ------------------------------------------------------------------------ */
+#define IDX3(P, ix, iy, iz) ((size_t)((ix)-1) + (size_t)(P)->nx * ((size_t)((iy)-1) + (size_t)(P)->ny * (size_t)((iz)-1)))
+#define IDX4(P, ix, iy, iz, ic) (IDX3(P, ix, iy, iz) + (size_t)(P)->nx * (P)->ny * (P)->nz * (size_t)((ic)-1))
+
+float orc_accumulate_extinction(const orc_problem *P, const float dir[3], double pos[3], int32_t idx[3],
+                                int hasTarget, float extToAccumulate, int64_t *crossings) {
+  const double *edge[3] = {P->xe, P->ye, P->ze};
+  const int ncell[3] = {P->nx, P->ny, P->nz};
+  float extAccumulated = 0.0f;
+  int side[3], inc[3];
+  for (int a = 0; a < 3; a++) { /* :1690-1692 */
+    side[a] = dir[a] >= 0.0f ? 1 : 0;
+    inc[a] = dir[a] >= 0.0f ? 1 : -1;
+  }
+  double z0 = P->ze[0], zMax = P->ze[P->nz];
+  for (;;) {
+    double step[3];
+    for (int a = 0; a < 3; a++) { /* :1705-1712 */
+      if (fabsf(dir[a]) >= 2.0f * FLT_MIN)
+        step[a] = (edge[a][idx[a] + side[a] - 1] - pos[a]) / (double)dir[a];
+      else
+        step[a] = DBL_MAX;
+    }
+    double thisStep = step[0];
+    if (step[1] < thisStep) thisStep = step[1];
+    if (step[2] < thisStep) thisStep = step[2];
+    if (thisStep <= 0.0) { extAccumulated = -2.0f; break; } /* :1719-1722 */
+    double thisCellExt = P->totalExt[IDX3(P, idx[0], idx[1], idx[2])];
+    if (hasTarget) { /* :1729-1739 */
+      if ((double)extAccumulated + thisStep * thisCellExt > (double)extToAccumulate) {
+        thisStep = (double)(extToAccumulate - extAccumulated) / thisCellExt;
+        pos[0] = pos[0] + thisStep * (double)dir[0];
+        pos[1] = pos[1] + thisStep * (double)dir[1];
+        pos[2] = pos[2] + thisStep * (double)dir[2];
+        extAccumulated = extToAccumulate;
+        break;
+      }
+    }
+    extAccumulated = (float)((double)extAccumulated + thisStep * thisCellExt); /* :1743 */
+    if (crossings) (*crossings)++;
+    for (int a = 0; a < 3; a++) { /* :1752-1777 */
+      if (step[a] <= thisStep) {
+        pos[a] = edge[a][idx[a] + side[a] - 1];
+        idx[a] += inc[a];
+      } else {
+        pos[a] = pos[a] + thisStep * (double)dir[a];
+        if (fabs(edge[a][idx[a] + side[a] - 1] - pos[a]) <= 2.0 * spacing_d(pos[a])) idx[a] += inc[a];
+      }
+    }
+    /* periodicity :1782-1796 (y uses cellIncrement(1), sic) */
+    for (int a = 0; a < 2; a++) {
+      if (idx[a] <= 0) {
+        idx[a] = ncell[a];
+        pos[a] = edge[a][idx[a]] + (double)(inc[0] * 2) * spacing_d(pos[a]);
+      } else if (idx[a] >= ncell[a] + 1) {
+        idx[a] = 1;
+        pos[a] = edge[a][0] + (double)(inc[0] * 2) * spacing_d(pos[a]);
+      }
+    }
+    if (idx[2] > P->nz) { pos[2] = zMax + 2.0 * spacing_d(zMax); break; } /* :1801-1804 */
+    if (idx[2] < 1) { pos[2] = z0; break; }                               /* :1809-1812 */
+  }
+  return extAccumulated;
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/emissionAndBroadBandWeights.f95:424-550 emission_weightingNEW          */
+/* ------------------------------------------------------------------------ */
+int orc_emission_weighting(int nx, int ny, int nz, int nc, const double *xe, const double *ye,
+                           const double *ze, const double *temps, const double *totalExt,
+                           const double *cumExt, const double *ssa, double albedo, double lambda_um,
+                           double sfcTemp, double dLambda, double *voxelWeights, double *fracAtmsPower,
+                           double *totalFlux) {
+  const double h = (double)6.62606957e-34f; /* default-real literals, as written (:448-450) */
+  const double c = (double)2.99792458e+8f;
+  const double k = (double)1.3806488e-23f;
+  const double a = 2.0 * h * pow(c, 2.0);
+  const double Pi = 4.0 * atan(1.0);
+  size_t nvox = (size_t)nx * ny * nz;
+  double emiss = 1.0 - albedo;
+  double lambda = lambda_um / pow(10.0, 6.0);
+  double b = h * c / (k * lambda);
+  double area = (xe[nx] - xe[0]) * (ye[ny] - ye[0]) * pow(1000.0, 2.0);
+  double sfcPower;
+  if (emiss == 0.0 || sfcTemp == 0.0) sfcPower = 0.0;
+  else {
+    double sfcPlanckRad = (a / (pow(lambda, 5.0) * (exp(b / sfcTemp) - 1.0))) / pow(10.0, 6.0);
+    sfcPower = Pi * emiss * sfcPlanckRad * (xe[nx] - xe[0]) * (ye[ny] - ye[0]) * pow(1000.0, 2.0);
+  }
+  double atmsPower = 0.0, previous = 0.0, corr = 0.0;
+  int allPositive = 1;
+  for (size_t i = 0; i < nvox; i++) if (temps[i] <= 0.0) allPositive = 0;
+  memset(voxelWeights, 0, sizeof(double) * nvox);
+  if (allPositive) {
+    for (int iz = 0; iz < nz; iz++) {
+      double dz = ze[iz + 1] - ze[iz];
+      for (int iy = 0; iy < ny; iy++)
+        for (int ix = 0; ix < nx; ix++) {
+          size_t v = (size_t)ix + (size_t)nx * ((size_t)iy + (size_t)ny * iz);
+          double planck = (a / (pow(lambda, 5.0) * (exp(b / temps[v]) - 1.0))) / pow(10.0, 6.0);
+          /* ext(:,:,:,j) = totalExt*(cumExt(j)-cumExt(j-1)) (opticalProperties.f95 getInfo_Domain) */
+          double s = 0.0;
+          for (int j = 0; j < nc; j++) {
+            double cj = cumExt[v + nvox * j], cjm = j > 0 ? cumExt[v + nvox * (j - 1)] : 0.0;
+            double extj = j == 0 ? totalExt[v] * cj : totalExt[v] * (cj - cjm);
+            s += ssa[v + nvox * j] * extj;
+          }
+          double totalAbsCoef = totalExt[v] - s;
+          double corr_contrib = (4.0 * Pi * planck * totalAbsCoef * dz) - corr; /* Kahan :503-507 */
+          double temp_sum = previous + corr_contrib;
+          corr = (temp_sum - previous) - corr_contrib;
+          previous = temp_sum;
+          voxelWeights[v] = previous;
+        }
+    }
+  }
+  *fracAtmsPower = 0.0;
+  double last = voxelWeights[nvox - 1];
+  if (last > 0.0) { /* :513-520 */
+    atmsPower = last * (xe[nx] - xe[0]) * (ye[ny] - ye[0]) * pow(1000.0, 2.0) / (double)(nx * ny);
+    for (size_t i = 0; i < nvox; i++) voxelWeights[i] = voxelWeights[i] / last;
+    voxelWeights[nvox - 1] = 1.0;
+    *fracAtmsPower = atmsPower / (atmsPower + sfcPower);
+  }
+  double totalPower = atmsPower + sfcPower;
+  if (totalPower == 0.0) return 1;
+  if (totalFlux) *totalFlux = (totalPower / area) * dLambda; /* :536-543 */
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/monteCarloIllumination.f95: one photon of a stream                    */
+/* ------------------------------------------------------------------------ */
+typedef struct { double x, y, z; float mu, phi; } launch_t;
+
+static void launch_directional(const orc_source *S, orc_rng *R, launch_t *L) { /* :88-96 */
+  L->x = (double)orc_random_real(R);
+  L->y = (double)orc_random_real(R);
+  L->z = (double)(1.0f - spacing_f(1.0f));
+  L->mu = -fabsf(S->solarMu);
+  L->phi = (S->solarAzimuthDeg * acosf(-1.0f)) / 180.0f;
+}
+
+static void launch_bbemission(const orc_problem *P, const orc_source *S, orc_rng *R, launch_t *L) { /* :481-516 */
+  int nx = P->nx, ny = P->ny, nz = P->nz;
+  float RN = orc_random_real(R);
+  if ((double)RN > S->fracAtmsPower) { /* surface :484-493 */
+    L->x = (double)orc_random_real(R);
+    L->y = (double)orc_random_real(R);
+    for (;;) {
+      L->mu = sqrtf(orc_random_real(R));
+      if (fabsf(L->mu) > 2.0f * FLT_MIN) break;
+    }
+    L->phi = (orc_random_real(R) * 2.0f) * acosf(-1.0f);
+    L->z = 0.0;
+  } else { /* atmosphere :495-510 */
+    RN = orc_random_real(R);
+    const double *vw = S->voxelWeights;
+    /* levelWeights(k)=vW(nx,ny,k); colWeights(j,k)=vW(nx,j,k) (emissionAndBroadBandWeights.f95:56-57) */
+    int ik = find_cdf_index_strided(RN, vw + ((size_t)nx - 1) + (size_t)nx * ((size_t)ny - 1), nz, (int64_t)nx * ny);
+    int ij = find_cdf_index_strided(RN, vw + ((size_t)nx - 1) + (size_t)nx * ny * ((size_t)ik - 1), ny, nx);
+    int ii = find_cdf_index_strided(RN, vw + (size_t)nx * (((size_t)ij - 1) + (size_t)ny * ((size_t)ik - 1)), nx, 1);
+    L->z = ((double)(ik - 1) * 1.0 / (double)nz) + (double)(orc_random_real(R) / (float)nz);
+    if (ik == 1 && L->z == 0.0) L->z = 0.0 + spacing_d(1.0);
+    if (ik == nz && L->z > 1.0 - 2.0 * spacing_d(1.0)) L->z = L->z - (2.0 * spacing_d(1.0));
+    L->x = ((double)(ii - 1) * 1.0 / (double)nx) + (double)(orc_random_real(R) * (1.0f / (float)nx));
+    L->y = ((double)(ij - 1) * 1.0 / (double)ny) + (double)(orc_random_real(R) * (1.0f / (float)ny));
+    for (;;) {
+      L->mu = 1.0f - (2.0f * orc_random_real(R));
+      if (fabsf(L->mu) > 2.0f * FLT_MIN) break;
+    }
+    L->phi = (orc_random_real(R) * 2.0f) * acosf(-1.0f);
+  }
+}
+
+static void launch_one(const orc_problem *P, const orc_source *S, orc_rng *R, launch_t *L) {
+  if (S->kind == 0) launch_directional(S, R, L);
+  else launch_bbemission(P, S, R, L);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Integrators/monteCarloRadiativeTransfer.f95 helpers                       */
+/* ------------------------------------------------------------------------ */
+void orc_grid_flags(const orc_problem *P, int *xyRegular, int *zRegular, double *deltaX, double *deltaY,
+                    double *deltaZ) { /* new_Integrator :163-181; note the float locals at :140 */
+  float dX = (float)(P->xe[1] - P->xe[0]);
+  float dY = (float)(P->ye[1] - P->ye[0]);
+  float dZ = (float)(P->ze[1] - P->ze[0]);
+  int xr = 1, yr = 1, zr = 1;
+  for (int i = 0; i < P->nx; i++)
+    if (!(fabs((P->xe[i + 1] - P->xe[i]) - (double)dX) <= 2.0 * spacing_d(P->xe[i + 1]))) xr = 0;
+  for (int i = 0; i < P->ny; i++)
+    if (!(fabs((P->ye[i + 1] - P->ye[i]) - (double)dY) <= 2.0 * spacing_d(P->ye[i + 1]))) yr = 0;
+  for (int i = 0; i < P->nz; i++)
+    if (!(fabs((P->ze[i + 1] - P->ze[i]) - (double)dZ) <= spacing_d(P->ze[i + 1]))) zr = 0;
+  *xyRegular = xr && yr;
+  *zRegular = zr;
+  *deltaX = *xyRegular ? (double)dX : 0.0;
+  *deltaY = *xyRegular ? (double)dY : 0.0;
+  *deltaZ = zr ? (double)dZ : 0.0;
+}
+
+static void make_direction_cosines(float mu, float phi, float d[3]) { /* :1876-1894 */
+  float sinTheta = sqrtf(1.0f - mu * mu);
+  float cosPhi = cosf(phi);
+  float sinPhi = sinf(phi);
+  d[0] = sinTheta * cosPhi;
+  d[1] = sinTheta * sinPhi;
+  d[2] = mu;
+}
+
+static float compute_scattering_angle(float u, const float *tbl, int n) { /* :1594-1621 */
+  int angleIndex = (int)(u * (float)n) + 1;
+  if (angleIndex < n) {
+    float leftOver = u - (float)(angleIndex - 1) / (float)n;
+    return (1.0f - leftOver) * tbl[angleIndex - 1] + leftOver * tbl[angleIndex];
+  }
+  return tbl[n - 1];
+}
+
+static void next_direct(orc_rng *R, float scatteringCosine, float S[3]) { /* :1921-1948 */
+  float D = 2.0f, AX = 0.f, AY = 0.f, B;
+  while (D > 1.0f) {
+    AX = 1.0f - 2.0f * orc_random_real(R);
+    AY = 1.0f - 2.0f * orc_random_real(R);
+    D = AX * AX + AY * AY;
+  }
+  B = sqrtf((1.0f - scatteringCosine * scatteringCosine) / D);
+  AX = AX * B;
+  AY = AY * B;
+  B = S[0] * AX - S[1] * AY;
+  D = scatteringCosine - B / (1.0f + fabsf(S[2]));
+  S[0] = S[0] * D + AX;
+  S[1] = S[1] * D - AY;
+  S[2] = S[2] * scatteringCosine - copysignf(fabsf(B), S[2] * B);
+}
+
+typedef struct { int xyRegular, zRegular; double dX, dY, dZ; } grid_flags;
+
+static void find_xy_indices(const orc_problem *P, const grid_flags *G, double xPos, double yPos,
+                            int *xIndex, int *yIndex) { /* :1551-1578 */
+  int nx = P->nx, ny = P->ny;
+  if (G->xyRegular) {
+    int xi = (int)((xPos - P->xe[0]) / G->dX) + 1; if (xi > nx) xi = nx;
+    int yi = (int)((yPos - P->ye[0]) / G->dY) + 1; if (yi > ny) yi = ny;
+    if (fabs(P->xe[xi] - xPos) < spacing_d(xPos)) xi++;
+    if (fabs(P->ye[yi] - yPos) < spacing_d(yPos)) yi++;
+    if (xi == nx + 1) xi = 1;
+    if (yi == ny + 1) yi = 1;
+    *xIndex = xi; *yIndex = yi;
+  } else {
+    int xi = orc_find_index_double(xPos, P->xe, nx + 1, *xIndex);
+    int yi = orc_find_index_double(yPos, P->ye, ny + 1, *yIndex);
+    if (fabs(P->xe[xi - 1] - xPos) < spacing_d(xPos)) xi++;
+    if (fabs(P->ye[yi - 1] - yPos) < spacing_d(yPos)) yi++;
+    if (xi >= nx + 1) xi = 1;
+    if (yi >= ny + 1) yi = 1;
+    *xIndex = xi; *yIndex = yi;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* computeRT :393-841                                                        */
+/* ------------------------------------------------------------------------ */
+int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, int64_t numPhotons,
+                       float *fluxUp, float *fluxDown, float *fluxAbsorbed, float *volumeAbsorption,
+                       orc_counters *C, orc_fate *fates) {
+  const int nx = P->nx, ny = P->ny, nz = P->nz, nc = P->nc;
+  const size_t ncol = (size_t)nx * ny, nvox = ncol * nz;
+  const float Pi = 3.14159265358979312f; /* :31 */
+  const float RussianRouletteW = 1.0f;   /* :56 */
+  orc_counters cnt;
+  memset(&cnt, 0, sizeof(cnt));
+  memset(fluxUp, 0, sizeof(float) * ncol);        /* computeRadiativeTransfer :248-252 */
+  memset(fluxDown, 0, sizeof(float) * ncol);
+  memset(fluxAbsorbed, 0, sizeof(float) * ncol);
+  memset(volumeAbsorption, 0, sizeof(float) * nvox);
+
+  grid_flags G;
+  orc_grid_flags(P, &G.xyRegular, &G.zRegular, &G.dX, &G.dY, &G.dZ);
+  const double x0 = P->xe[0], xMax = P->xe[nx];
+  const double y0 = P->ye[0], yMax = P->ye[ny];
+  const double z0 = P->ze[0], zMax = P->ze[nz];
+  const double albedo = P->albedo;
+
+  /* MT mode: the whole stream is generated first (new_PhotonStream), as the
+   * driver does (monteCarloDriver.f95:950-957), then traced. */
+  launch_t *stream = NULL;
+  if (R->mode == 0) {
+    stream = (launch_t *)malloc(sizeof(launch_t) * (size_t)(numPhotons > 0 ? numPhotons : 1));
+    for (int64_t i = 0; i < numPhotons; i++) launch_one(P, S, R, &stream[i]);
+  }
+  uint64_t drawsAtStart = R->ndraws;
+
+  int64_t nPhotons = 0;
+  for (int64_t ip = 0; ip < numPhotons; ip++) { /* photonLoop :463 */
+    launch_t L;
+    uint64_t photonDraws0;
+    if (R->mode == 0) { L = stream[ip]; photonDraws0 = R->ndraws; }
+    else {
+      philox_start_photon(R, R->firstPhoton + (uint64_t)ip);
+      photonDraws0 = R->ndraws;
+      launch_one(P, S, R, &L);
+    }
+    double xPos = L.x, yPos = L.y, zPos = L.z;
+    float mu = L.mu, phi = L.phi;
+    int scatteringOrder = 0;
+    float dir[3];
+    make_direction_cosines(mu, phi, dir); /* :471 */
+    float photonWeight = 1.0f;
+    nPhotons++;
+    int xIndex = 1, yIndex = 1, zIndex = 1; /* :478 */
+    xPos = x0 + xPos * (xMax - x0);
+    yPos = y0 + yPos * (yMax - y0);
+    find_xy_indices(P, &G, xPos, yPos, &xIndex, &yIndex);
+    if (G.zRegular) { /* :484-486, findZIndex :1580-1592 */
+      zPos = z0 + zPos * (zMax - z0);
+      zIndex = (int)((zPos - z0) / G.dZ) + 1; if (zIndex > nz) zIndex = nz;
+      if (fabs(P->ze[zIndex] - zPos) < spacing_d(zPos)) zIndex++;
+    } else { /* :491-493 */
+      double t = (zPos - z0) * (double)nz;
+      double remainder = t - floor(t);
+      zIndex = (int)floor(t) + 1; if (zIndex > nz) zIndex = nz;
+      zPos = P->ze[zIndex - 1] + remainder * (P->ze[zIndex] - P->ze[zIndex - 1]);
+    }
+    if (P->lwFlag > 0.0f) { /* :504-508 */
+      if (zPos > 0.0) {
+        size_t c2 = (size_t)(xIndex - 1) + (size_t)nx * (yIndex - 1);
+        fluxAbsorbed[c2] = fluxAbsorbed[c2] - 1.0f;
+        size_t v3 = IDX3(P, xIndex, yIndex, zIndex);
+        volumeAbsorption[v3] = volumeAbsorption[v3] - 1.0f;
+      }
+    }
+    int fate = -1;
+    float fateWeight = 0.0f;
+    for (;;) { /* scatteringLoop :548 */
+      float u = orc_random_real(R);
+      float tauToTravel = -logf(u > FLT_MIN ? u : FLT_MIN); /* :554 */
+      cnt.legs++;
+      double pos[3] = {xPos, yPos, zPos};
+      int32_t idx[3] = {xIndex, yIndex, zIndex};
+      float tauAccumulated = orc_accumulate_extinction(P, dir, pos, idx, 1, tauToTravel, &cnt.crossings);
+      xPos = pos[0]; yPos = pos[1]; zPos = pos[2];
+      xIndex = idx[0]; yIndex = idx[1]; zIndex = idx[2];
+      if (tauAccumulated < 0.0f) { cnt.badPhotons++; fate = 3; break; } /* :562-563 */
+
+      if (zPos >= zMax) { /* :573-617 */
+        size_t c2 = (size_t)(xIndex - 1) + (size_t)nx * (yIndex - 1);
+        fluxUp[c2] = fluxUp[c2] + photonWeight;
+        cnt.topExits++;
+        fate = 0; fateWeight = photonWeight;
+        break;
+      } else if (zPos <= z0 + spacing_d(z0)) { /* :619-676 */
+        zIndex = 1;
+        zPos = z0 + spacing_d(z0);
+        size_t c2 = (size_t)(xIndex - 1) + (size_t)nx * (yIndex - 1);
+        fluxDown[c2] = fluxDown[c2] + photonWeight;
+        cnt.surfaceHits++;
+        scatteringOrder++;
+        for (;;) {
+          mu = sqrtf(orc_random_real(R));
+          if (fabsf(mu) > 2.0f * FLT_MIN) break;
+        }
+        phi = (2.0f * Pi) * orc_random_real(R);
+        float wBefore = photonWeight;
+        photonWeight = (float)((double)photonWeight * albedo); /* :673 */
+        if (photonWeight <= FLT_MIN) { cnt.surfaceAbsorbed++; fate = 1; fateWeight = wBefore; break; }
+        make_direction_cosines(mu, phi, dir);
+      } else { /* scattering event :703-821 */
+        scatteringOrder++;
+        cnt.collisions++;
+        if (P->totalExt[IDX3(P, xIndex, yIndex, zIndex)] <= 0.0) { /* :728-754 */
+          if (xPos - P->xe[xIndex - 1] <= 0.0 && dir[0] > 0.0f) {
+            xPos = xPos - spacing_d(xPos);
+            xIndex = xIndex - 1;
+            if (xIndex <= 0) {
+              xIndex = nx;
+              xPos = P->xe[xIndex - 1];
+              xPos = xPos - 2.0 * spacing_d(xPos);
+            }
+          }
+          if (yPos - P->ye[yIndex - 1] <= 0.0 && dir[1] > 0.0f) {
+            yPos = yPos - spacing_d(yPos);
+            yIndex = yIndex - 1;
+            if (yIndex <= 0) {
+              yIndex = ny;
+              /* :743 uses xPosition(yIndex) (sic); guarded so the C does not read out of bounds */
+              yPos = (yIndex <= nx + 1) ? P->xe[yIndex - 1] : P->ye[yIndex - 1];
+              yPos = yPos - 2.0 * spacing_d(yPos);
+            }
+          }
+          if (zPos - P->ze[zIndex - 1] <= 0.0 && dir[2] > 0.0f) {
+            zPos = zPos - spacing_d(zPos);
+            zIndex = zIndex - 1;
+          }
+          if (zIndex < 1) { cnt.badPhotons++; fate = 3; break; } /* reference would index out of bounds */
+        }
+        double tbl[ORC_MAX_COMPONENTS + 1];
+        tbl[0] = 0.0;
+        for (int c = 1; c <= nc; c++) tbl[c] = P->cumExt[IDX4(P, xIndex, yIndex, zIndex, c)];
+        int component = orc_find_index_mixed(orc_random_real(R), tbl, nc + 1, 0); /* :759-760 */
+        if (component < 1) component = 1;
+        if (component > nc) component = nc;
+        float ssa = (float)P->ssa[IDX4(P, xIndex, yIndex, zIndex, component)]; /* :764 */
+        if ((double)ssa < 1.0) { /* :765-771 */
+          size_t c2 = (size_t)(xIndex - 1) + (size_t)nx * (yIndex - 1);
+          size_t v3 = IDX3(P, xIndex, yIndex, zIndex);
+          fluxAbsorbed[c2] = (float)((double)fluxAbsorbed[c2] + (double)photonWeight * (1.0 - (double)ssa));
+          volumeAbsorption[v3] = (float)((double)volumeAbsorption[v3] + (double)photonWeight * (1.0 - (double)ssa));
+          photonWeight = photonWeight * ssa;
+          cnt.absorbEvents++;
+        }
+        if (P->useRussianRoulette && photonWeight < RussianRouletteW / 2.0f) { /* :805-811 */
+          if (orc_random_real(R) >= photonWeight / RussianRouletteW) { photonWeight = 0.0f; cnt.rouletteKills++; }
+          else { photonWeight = RussianRouletteW; cnt.rouletteSurvivals++; }
+        }
+        if (photonWeight <= FLT_MIN) { fate = 2; break; } /* :812 */
+        int pfi = P->pfIndex[IDX4(P, xIndex, yIndex, zIndex, component)]; /* :816 */
+        int ns = P->invNSteps[component - 1];
+        const float *tblf = P->invTables + P->invOffset[component - 1] + (size_t)(pfi - 1) * ns;
+        float scatteringAngle = compute_scattering_angle(orc_random_real(R), tblf, ns);
+        next_direct(R, cosf(scatteringAngle), dir); /* :819 */
+      }
+    }
+    if (fates) {
+      fates[ip].fate = fate;
+      fates[ip].ix = xIndex; fates[ip].iy = yIndex; fates[ip].iz = zIndex;
+      fates[ip].nScatter = scatteringOrder;
+      fates[ip].nDraws = (int32_t)(R->ndraws - photonDraws0);
+      fates[ip].weight = fateWeight;
+    }
+  }
+  cnt.draws = R->ndraws - drawsAtStart;
+  if (C) *C = cnt;
+  free(stream);
+  return nPhotons;
+}
+
+/* computeRadiativeTransfer :328-364 */
+void orc_normalize(const orc_problem *P, int64_t numPhotonsProcessed, float *fluxUp, float *fluxDown,
+                   float *fluxAbsorbed, float *volumeAbsorption) {
+  int nx = P->nx, ny = P->ny, nz = P->nz;
+  size_t ncol = (size_t)nx * ny;
+  grid_flags G;
+  orc_grid_flags(P, &G.xyRegular, &G.zRegular, &G.dX, &G.dY, &G.dZ);
+  float *nppc = (float *)malloc(sizeof(float) * ncol);
+  if (G.xyRegular) {
+    float v = (float)numPhotonsProcessed / (float)(nx * ny); /* :331 */
+    for (size_t i = 0; i < ncol; i++) nppc[i] = v;
+  } else {
+    for (int j = 0; j < ny; j++)
+      for (int i = 0; i < nx; i++) { /* :334-342 */
+        double rel = ((P->ye[j + 1] - P->ye[j]) * (P->xe[i + 1] - P->xe[i])) /
+                     ((P->xe[nx] - P->xe[0]) * (P->ye[ny] - P->ye[0]));
+        float r = (float)rel;
+        nppc[(size_t)i + (size_t)nx * j] = r * (float)numPhotonsProcessed;
+      }
+  }
+  for (size_t i = 0; i < ncol; i++) {
+    fluxUp[i] = fluxUp[i] / nppc[i];
+    fluxDown[i] = fluxDown[i] / nppc[i];
+    fluxAbsorbed[i] = fluxAbsorbed[i] / nppc[i];
+  }
+  for (int k = 0; k < nz; k++) { /* :361-364 */
+    double dz = P->ze[k + 1] - P->ze[k];
+    for (size_t i = 0; i < ncol; i++) {
+      size_t v = i + ncol * k;
+      volumeAbsorption[v] = (float)((double)volumeAbsorption[v] / (((double)nppc[i] * dz) * 1000.0));
+    }
+  }
+  free(nppc);
+}
+
+/* reportResults :877-884, :966 */
+void orc_report_means(const orc_problem *P, const float *fluxUp, const float *fluxDown,
+                      const float *fluxAbsorbed, const float *volumeAbsorption, float *meanUp,
+                      float *meanDown, float *meanAbs, float *absorbedProfile) {
+  size_t ncol = (size_t)P->nx * P->ny;
+  float su = 0.f, sd = 0.f, sa = 0.f;
+  for (size_t i = 0; i < ncol; i++) { su += fluxUp[i]; sd += fluxDown[i]; sa += fluxAbsorbed[i]; }
+  if (meanUp) *meanUp = su / (float)ncol;
+  if (meanDown) *meanDown = sd / (float)ncol;
+  if (meanAbs) *meanAbs = sa / (float)ncol;
+  if (absorbedProfile)
+    for (int k = 0; k < P->nz; k++) {
+      float s = 0.f;
+      for (size_t i = 0; i < ncol; i++) s += volumeAbsorption[i + ncol * k];
+      absorbedProfile[k] = s / (float)ncol;
+    }
+}
