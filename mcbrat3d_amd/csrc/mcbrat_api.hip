@@ -1,0 +1,549 @@
+// mcbrat_api.hip -- C ABI (include/mcbrat.h) over the gfx950 kernels.  Host plumbing only:
+// device buffers, launches on one HIP stream per context, HIP-event timing.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mcbrat_kernels.hip"
+
+using namespace mcbrat;
+
+struct mcbrat_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  int numCUs = 256;
+  // grid
+  int nx = 0, ny = 0, nz = 0, nc = 0;
+  bool haveGrid = false, haveOptics = false, haveSource = false;
+  std::vector<double> xe, ye, ze;
+  int xyRegular = 0, zRegular = 0;
+  double dX = 0, dY = 0, dZ = 0;
+  // device buffers
+  double *dEdges = nullptr;
+  float *dExt = nullptr, *dCum = nullptr, *dSsa = nullptr, *dRelArea = nullptr;
+  uint16_t *dPfi = nullptr;
+  float *dTables = nullptr;
+  double *dVoxelCDF = nullptr;
+  unsigned long long *dCounter = nullptr, *dEventCounters = nullptr;
+  long long *dSlabs = nullptr;
+  size_t slabCapacity = 0;  // batches
+  float *dColVals = nullptr, *dScalVals = nullptr, *dLast = nullptr;
+  size_t finishCapacity = 0;
+  double *dMomentsOwned = nullptr, *dMoments = nullptr;
+  // tables (host, per component)
+  std::vector<std::vector<float>> tables;
+  std::vector<int> tblNSteps, tblNEntries;
+  std::vector<int> maxPfi;  // largest 0-based entry referenced per component
+  bool tablesDirty = true;
+  int tblTotalFloats = 0;
+  int tblOffset[MCBRAT_MAX_COMPONENTS] = {0};
+  // parameters
+  float albedo = 0.f;
+  int useRR = 1;
+  float lwFlag = -1.f;
+  int srcKind = 0;
+  float dir0[3] = {0, 0, -1};
+  double zLaunch = 0;
+  int izLaunch = 0;
+  double fracAtms = 0;
+  // tuning / measurement
+  int blocksPerCU = 0;  // 0: from the occupancy query
+  int eventThreshold = 40;
+  int maxBatchesInFlight = 0;  // 0: bounded by memory
+  bool countersOn = false;
+  float lastTraceMs = 0.f;
+  mcbrat_counters lastCounters{};
+  bool haveLast = false;
+};
+
+namespace {
+
+int fail(mcbrat_ctx *c, const std::string &msg) {
+  if (c) c->err = msg;
+  return 1;
+}
+#define HIP_OK(c, call)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (call);                                                                               \
+    if (e_ != hipSuccess) return fail(c, std::string(#call) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+
+double spacing_d(double x) {
+  if (x == 0.0) return DBL_MIN;
+  int e;
+  std::frexp(std::fabs(x), &e);
+  const double s = std::ldexp(1.0, e - 53);
+  return s < DBL_MIN ? DBL_MIN : s;
+}
+
+template <typename T>
+int upload(mcbrat_ctx *c, T **dst, const T *src, size_t n) {
+  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+  HIP_OK(c, hipMalloc((void **)dst, sizeof(T) * std::max<size_t>(n, 1)));
+  if (n) HIP_OK(c, hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+long long moments_len(const mcbrat_ctx *c) {
+  const long long ncol = (long long)c->nx * c->ny;
+  return 3 + 3 * ncol + c->nz + ncol * c->nz;
+}
+
+int ensure_moments(mcbrat_ctx *c) {
+  if (c->dMoments) return 0;
+  const size_t n = 8 + 2 * (size_t)moments_len(c);
+  HIP_OK(c, hipMalloc((void **)&c->dMomentsOwned, sizeof(double) * n));
+  HIP_OK(c, hipMemset(c->dMomentsOwned, 0, sizeof(double) * n));
+  c->dMoments = c->dMomentsOwned;
+  return 0;
+}
+
+int sync_tables(mcbrat_ctx *c) {
+  if (!c->tablesDirty) return 0;
+  std::vector<float> all;
+  for (int k = 0; k < c->nc; ++k) {
+    if ((int)c->tables.size() <= k || c->tables[k].empty())
+      return fail(c, "computeRadiativeTransfer: no inverse phase function table for component " + std::to_string(k + 1));
+    if (c->maxPfi[k] >= c->tblNEntries[k])
+      return fail(c, "computeRadiativeTransfer: phaseFunctionIndex exceeds table entries for component " + std::to_string(k + 1));
+    c->tblOffset[k] = (int)all.size();
+    all.insert(all.end(), c->tables[k].begin(), c->tables[k].end());
+  }
+  c->tblTotalFloats = (int)all.size();
+  if (upload(c, &c->dTables, all.data(), all.size())) return 1;
+  c->tablesDirty = false;
+  return 0;
+}
+
+void fill_params(mcbrat_ctx *c, DevParams &p) {
+  std::memset(&p, 0, sizeof(p));
+  p.nx = c->nx; p.ny = c->ny; p.nz = c->nz; p.nc = c->nc;
+  p.xyRegular = c->xyRegular; p.zRegular = c->zRegular;
+  p.x0 = c->xe.front(); p.xMax = c->xe.back();
+  p.y0 = c->ye.front(); p.yMax = c->ye.back();
+  p.z0 = c->ze.front(); p.zMax = c->ze.back();
+  p.Lx = p.xMax - p.x0; p.Ly = p.yMax - p.y0;
+  p.zSurf = p.z0 + spacing_d(p.z0);
+  p.invDX = c->xyRegular ? 1.0 / c->dX : 0.0;
+  p.invDY = c->xyRegular ? 1.0 / c->dY : 0.0;
+  p.edges = c->dEdges;
+  p.ext = c->dExt; p.cum = c->dCum; p.ssa = c->dSsa; p.pfi = c->dPfi;
+  p.albedo = c->albedo;
+  p.tables = c->dTables;
+  for (int k = 0; k < c->nc; ++k) { p.tblOffset[k] = c->tblOffset[k]; p.tblNSteps[k] = c->tblNSteps[k]; }
+  p.tblTotalFloats = c->tblTotalFloats;
+  p.useRR = c->useRR;
+  p.lwFlag = c->lwFlag > 0.f ? 1 : 0;
+  p.srcKind = c->srcKind;
+  p.dir0[0] = c->dir0[0]; p.dir0[1] = c->dir0[1]; p.dir0[2] = c->dir0[2];
+  p.zLaunch = c->zLaunch; p.izLaunch = c->izLaunch;
+  p.voxelCDF = c->dVoxelCDF; p.fracAtms = c->fracAtms;
+  p.counter = c->dCounter;
+  p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
+}
+
+size_t lds_bytes(const mcbrat_ctx *c, bool tblLds) {
+  size_t b = sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3);
+  if (tblLds) b += sizeof(float) * (size_t)c->tblTotalFloats;
+  return b;
+}
+constexpr size_t kTableLdsLimit = 48 * 1024;  // above this the tables stay in L2
+
+template <bool TBL, bool DBG>
+int launch_trace_t(mcbrat_ctx *c, const DevParams &p, size_t lds) {
+  int perCU = c->blocksPerCU;
+  if (perCU <= 0) {
+    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<TBL, DBG>, kBlock, lds));
+    perCU = std::max(1, std::min(perCU, 8));
+  }
+  unsigned long long needed = (p.total + kBlock - 1) / kBlock;
+  unsigned grid = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)perCU * c->numCUs, needed));
+  hipLaunchKernelGGL((trace_kernel<TBL, DBG>), dim3(grid), dim3(kBlock), lds, c->stream, p);
+  HIP_OK(c, hipGetLastError());
+  return 0;
+}
+
+int launch_trace(mcbrat_ctx *c, const DevParams &p, bool debug) {
+  const bool tblLds = sizeof(float) * (size_t)c->tblTotalFloats <= kTableLdsLimit;
+  const size_t lds = lds_bytes(c, tblLds);
+  if (tblLds) return debug ? launch_trace_t<true, true>(c, p, lds) : launch_trace_t<true, false>(c, p, lds);
+  return debug ? launch_trace_t<false, true>(c, p, lds) : launch_trace_t<false, false>(c, p, lds);
+}
+
+int check_ready(mcbrat_ctx *c) {
+  if (!c) return 1;
+  if (!c->haveGrid || !c->haveOptics) return fail(c, "computeRadiativeTransfer: problem not completely specified.");
+  if (!c->haveSource) return fail(c, "computeRadiativeTransfer: no photon source set.");
+  return sync_tables(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcbrat_abi_version(void) { return MCBRAT_ABI_VERSION; }
+
+mcbrat_ctx *mcbrat_create(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  mcbrat_ctx *c = new mcbrat_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCUs = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipMalloc((void **)&c->dCounter, sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void **)&c->dEventCounters, 8 * sizeof(unsigned long long)) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+void mcbrat_destroy(mcbrat_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF, c->dCounter,
+                  c->dEventCounters, c->dSlabs, c->dColVals, c->dScalVals, c->dLast, c->dMomentsOwned};
+  for (void *b : bufs) if (b) (void)hipFree(b);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *mcbrat_last_error(const mcbrat_ctx *c) { return c ? c->err.c_str() : "mcbrat: no context (no usable HIP device)"; }
+
+int mcbrat_set_grid(mcbrat_ctx *c, int32_t nx, int32_t ny, int32_t nz, const double *xe, const double *ye,
+                    const double *ze) {
+  if (!c) return 1;
+  if (nx < 1 || ny < 1 || nz < 1 || !xe || !ye || !ze) return fail(c, "new_Integrator: Problems reading domain.");
+  for (int i = 0; i < nx; ++i) if (!(xe[i + 1] > xe[i])) return fail(c, "new_Domain: x edges must be increasing, unique.");
+  for (int i = 0; i < ny; ++i) if (!(ye[i + 1] > ye[i])) return fail(c, "new_Domain: y edges must be increasing, unique.");
+  for (int i = 0; i < nz; ++i) if (!(ze[i + 1] > ze[i])) return fail(c, "new_Domain: z edges must be increasing, unique.");
+  (void)hipSetDevice(c->device);
+  c->nx = nx; c->ny = ny; c->nz = nz;
+  c->xe.assign(xe, xe + nx + 1); c->ye.assign(ye, ye + ny + 1); c->ze.assign(ze, ze + nz + 1);
+  // regular-spacing flags exactly as new_Integrator :163-181 (deltaX/Y/Z are default-real locals, :140)
+  const float fX = (float)(xe[1] - xe[0]), fY = (float)(ye[1] - ye[0]), fZ = (float)(ze[1] - ze[0]);
+  bool xr = true, yr = true, zr = true;
+  for (int i = 0; i < nx; ++i) xr = xr && std::fabs((xe[i + 1] - xe[i]) - (double)fX) <= 2.0 * spacing_d(xe[i + 1]);
+  for (int i = 0; i < ny; ++i) yr = yr && std::fabs((ye[i + 1] - ye[i]) - (double)fY) <= 2.0 * spacing_d(ye[i + 1]);
+  for (int i = 0; i < nz; ++i) zr = zr && std::fabs((ze[i + 1] - ze[i]) - (double)fZ) <= spacing_d(ze[i + 1]);
+  c->xyRegular = xr && yr; c->zRegular = zr;
+  c->dX = fX; c->dY = fY; c->dZ = fZ;
+  std::vector<double> edges;
+  edges.insert(edges.end(), c->xe.begin(), c->xe.end());
+  edges.insert(edges.end(), c->ye.begin(), c->ye.end());
+  edges.insert(edges.end(), c->ze.begin(), c->ze.end());
+  if (upload(c, &c->dEdges, edges.data(), edges.size())) return 1;
+  // relative column areas, computeRadiativeTransfer :334-340 (real(8) expression stored to default real)
+  std::vector<float> rel((size_t)nx * ny);
+  for (int j = 0; j < ny; ++j)
+    for (int i = 0; i < nx; ++i)
+      rel[(size_t)i + (size_t)nx * j] = (float)(((ye[j + 1] - ye[j]) * (xe[i + 1] - xe[i])) / ((xe[nx] - xe[0]) * (ye[ny] - ye[0])));
+  if (upload(c, &c->dRelArea, rel.data(), rel.size())) return 1;
+  c->haveGrid = true; c->haveOptics = false; c->haveSource = false; c->haveLast = false;
+  if (c->dMomentsOwned) { (void)hipFree(c->dMomentsOwned); c->dMomentsOwned = nullptr; }
+  c->dMoments = nullptr;
+  c->slabCapacity = 0; c->finishCapacity = 0;
+  return 0;
+}
+
+int mcbrat_set_optics(mcbrat_ctx *c, int32_t nc, const double *totalExt, const double *cumExt, const double *ssa,
+                      const int32_t *pfIndex, double albedo) {
+  if (!c) return 1;
+  if (!c->haveGrid) return fail(c, "getInfo_Domain: domain hasn't been initialized.");
+  if (nc < 1 || nc > MCBRAT_MAX_COMPONENTS) return fail(c, "getOpticalPropertiesByComponent: unsupported number of components.");
+  if (!totalExt || !cumExt || !ssa || !pfIndex) return fail(c, "getOpticalPropertiesByComponent: domain contains no optical components.");
+  (void)hipSetDevice(c->device);
+  const size_t nvox = (size_t)c->nx * c->ny * c->nz;
+  std::vector<float> e(nvox), cu(nvox * nc), s(nvox * nc);
+  std::vector<uint16_t> pf(nvox * nc);
+  std::vector<int> maxPfi(nc, 0);
+  for (size_t v = 0; v < nvox; ++v) {
+    if (!(totalExt[v] >= 0.0)) return fail(c, "validateOpticalComponent: extinction must be >= 0.");
+    e[v] = (float)totalExt[v];
+  }
+  for (int k = 0; k < nc; ++k)
+    for (size_t v = 0; v < nvox; ++v) {
+      const size_t i = (size_t)k * nvox + v;
+      if (totalExt[v] > 0.0 && !(ssa[i] >= 0.0 && ssa[i] <= 1.0)) return fail(c, "validateOpticalComponent: singleScatteringAlbedo must be between 0 and 1.");
+      cu[i] = (float)cumExt[i];
+      s[i] = (float)ssa[i];
+      int idx = pfIndex[i];
+      if (totalExt[v] > 0.0 && (idx < 1 || idx > 65535)) return fail(c, "validateOpticalComponent: phaseFunctionIndex out of range.");
+      if (idx < 1) idx = 1;
+      pf[i] = (uint16_t)(idx - 1);
+      if (totalExt[v] > 0.0) maxPfi[k] = std::max(maxPfi[k], idx - 1);
+    }
+  if (!(albedo >= 0.0 && albedo <= 1.0)) return fail(c, "new_Domain: surfaceAlbedo must be between 0 and 1.");
+  if (upload(c, &c->dExt, e.data(), e.size()) || upload(c, &c->dCum, cu.data(), cu.size()) ||
+      upload(c, &c->dSsa, s.data(), s.size()) || upload(c, &c->dPfi, pf.data(), pf.size()))
+    return 1;
+  c->nc = nc;
+  c->albedo = (float)albedo;
+  c->maxPfi = maxPfi;
+  c->tables.resize(nc); c->tblNSteps.resize(nc, 0); c->tblNEntries.resize(nc, 0);
+  c->tablesDirty = true;
+  c->haveOptics = true;
+  return 0;
+}
+
+int mcbrat_set_inverse_table(mcbrat_ctx *c, int32_t component, int32_t nSteps, int32_t nEntries, const float *table) {
+  if (!c) return 1;
+  if (!c->haveOptics) return fail(c, "tabulateInversePhaseFunctions: domain has no optical components yet.");
+  if (component < 1 || component > c->nc) return fail(c, "tabulateInversePhaseFunctions: failed on component" + std::to_string(component));
+  if (nSteps < 2 || nEntries < 1 || !table) return fail(c, "computeInversePhaseFunctionTable: Array for inverse table has the wrong number of entries");
+  c->tables[component - 1].assign(table, table + (size_t)nSteps * nEntries);
+  c->tblNSteps[component - 1] = nSteps;
+  c->tblNEntries[component - 1] = nEntries;
+  c->tablesDirty = true;
+  return 0;
+}
+
+int mcbrat_specify_parameters(mcbrat_ctx *c, int32_t useRayTracing, int32_t useRussianRoulette, float lwFlag) {
+  if (!c) return 1;
+  if (!useRayTracing)
+    return fail(c, "specifyParameters: useRayTracing=.false. (maximum cross-section) is not supported: "
+                   "that branch of the reference never refreshes the cell indices (SURVEY.md 8a quirk 4).");
+  c->useRR = useRussianRoulette ? 1 : 0;
+  c->lwFlag = lwFlag;
+  return 0;
+}
+
+int mcbrat_set_source_solar(mcbrat_ctx *c, float solarMu, float solarAzimuthDeg) {
+  if (!c) return 1;
+  if (!c->haveGrid) return fail(c, "setIllumination: domain hasn't been initialized.");
+  if (solarAzimuthDeg < 0.f || solarAzimuthDeg > 360.f) return fail(c, "setIllumination: solarAzimuth out of bounds");
+  if (std::fabs(solarMu) > 1.f || std::fabs(solarMu) <= FLT_MIN) return fail(c, "setIllumination: solarMu out of bounds");
+  // newPhotonStream_Directional, monteCarloIllumination.f95:93-96, then makeDirectionCosines :1876-1894
+  const float mu = -std::fabs(solarMu);
+  const float phi = (solarAzimuthDeg * std::acos(-1.0f)) / 180.0f;
+  const float sinTheta = std::sqrt(1.0f - mu * mu);
+  c->dir0[0] = sinTheta * std::cos(phi); c->dir0[1] = sinTheta * std::sin(phi); c->dir0[2] = mu;
+  // launch height z = 1 - spacing(1.) of the column (:93), mapped as computeRT :484-493
+  const double frac = (double)(1.0f - 1.1920929e-07f);
+  const double z0 = c->ze.front(), zMax = c->ze.back();
+  if (c->zRegular) {
+    c->zLaunch = z0 + frac * (zMax - z0);
+    int zi = (int)((c->zLaunch - z0) / c->dZ) + 1;
+    zi = std::min(zi, c->nz);
+    if (std::fabs(c->ze[zi] - c->zLaunch) < spacing_d(c->zLaunch)) zi++;
+    c->izLaunch = std::min(zi, c->nz) - 1;
+  } else {
+    const double t = (frac - z0) * (double)c->nz;
+    const double fl = std::floor(t);
+    int zi = std::min((int)fl + 1, c->nz);
+    zi = std::max(zi, 1);
+    c->izLaunch = zi - 1;
+    c->zLaunch = c->ze[zi - 1] + (t - fl) * (c->ze[zi] - c->ze[zi - 1]);
+  }
+  c->srcKind = 0;
+  c->haveSource = true;
+  return 0;
+}
+
+int mcbrat_set_source_emission(mcbrat_ctx *c, const double *voxelWeights, double fracAtmsPower) {
+  if (!c) return 1;
+  if (!c->haveGrid) return fail(c, "setIllumination: domain hasn't been initialized.");
+  if (!voxelWeights || !(fracAtmsPower >= 0.0 && fracAtmsPower <= 1.0)) return fail(c, "setIllumination: invalid emission weights.");
+  (void)hipSetDevice(c->device);
+  if (upload(c, &c->dVoxelCDF, voxelWeights, (size_t)c->nx * c->ny * c->nz)) return 1;
+  c->fracAtms = fracAtmsPower;
+  c->srcKind = 1;
+  c->haveSource = true;
+  return 0;
+}
+
+int64_t mcbrat_moments_length(const mcbrat_ctx *c) { return c && c->haveGrid ? moments_len(c) : 0; }
+
+int mcbrat_bind_moments(mcbrat_ctx *c, double *deviceBuffer) {
+  if (!c) return 1;
+  if (!c->haveGrid) return fail(c, "bind_moments: set the grid first.");
+  if (deviceBuffer) c->dMoments = deviceBuffer;
+  else { c->dMoments = c->dMomentsOwned; return ensure_moments(c); }
+  return 0;
+}
+
+int mcbrat_reset_moments(mcbrat_ctx *c) {
+  if (!c) return 1;
+  if (!c->haveGrid) return fail(c, "reset_moments: set the grid first.");
+  (void)hipSetDevice(c->device);
+  if (ensure_moments(c)) return 1;
+  HIP_OK(c, hipMemsetAsync(c->dMoments, 0, sizeof(double) * (8 + 2 * (size_t)moments_len(c)), c->stream));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mcbrat_get_moments(mcbrat_ctx *c, double *host) {
+  if (!c || !host) return 1;
+  (void)hipSetDevice(c->device);
+  if (ensure_moments(c)) return 1;
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  HIP_OK(c, hipMemcpy(host, c->dMoments, sizeof(double) * (8 + 2 * (size_t)moments_len(c)), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mcbrat_enable_counters(mcbrat_ctx *c, int32_t enable) {
+  if (!c) return 1;
+  c->countersOn = enable != 0;
+  return 0;
+}
+int mcbrat_get_counters(mcbrat_ctx *c, mcbrat_counters *out) {
+  if (!c || !out) return 1;
+  *out = c->lastCounters;
+  return 0;
+}
+float mcbrat_last_trace_ms(const mcbrat_ctx *c) { return c ? c->lastTraceMs : 0.f; }
+
+int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight) {
+  if (!c) return 1;
+  if (blocksPerCU >= 0) c->blocksPerCU = blocksPerCU;
+  if (eventThreshold > 0) c->eventThreshold = eventThreshold;
+  if (maxBatchesInFlight >= 0) c->maxBatchesInFlight = maxBatchesInFlight;
+  return 0;
+}
+
+int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int64_t ppb, int32_t nBatches,
+                                      int64_t *numPhotonsProcessed) {
+  if (!c) return 1;
+  (void)hipSetDevice(c->device);
+  if (check_ready(c)) return 1;
+  if (ppb < 1 || nBatches < 1) return fail(c, "computeRadiativeTransfer: Didn't process any photons.");
+  if (ensure_moments(c)) return 1;
+  const size_t ncol = (size_t)c->nx * c->ny, nvox = ncol * c->nz;
+  const size_t slabStride = 2 * ncol + nvox;
+  // batches in flight: bounded by a memory budget (slabs are 8 B per tally bin per batch)
+  size_t inFlight = std::max<size_t>(1, (size_t)(4ull << 30) / (slabStride * sizeof(long long)));
+  if (c->maxBatchesInFlight > 0) inFlight = std::min<size_t>(inFlight, (size_t)c->maxBatchesInFlight);
+  inFlight = std::min<size_t>(inFlight, (size_t)nBatches);
+  if (c->slabCapacity < inFlight) {
+    if (c->dSlabs) (void)hipFree(c->dSlabs);
+    c->dSlabs = nullptr;
+    HIP_OK(c, hipMalloc((void **)&c->dSlabs, sizeof(long long) * slabStride * inFlight));
+    c->slabCapacity = inFlight;
+  }
+  if (c->finishCapacity < inFlight) {
+    if (c->dColVals) (void)hipFree(c->dColVals);
+    if (c->dScalVals) (void)hipFree(c->dScalVals);
+    c->dColVals = c->dScalVals = nullptr;
+    HIP_OK(c, hipMalloc((void **)&c->dColVals, sizeof(float) * 3 * ncol * inFlight));
+    HIP_OK(c, hipMalloc((void **)&c->dScalVals, sizeof(float) * (3 + c->nz) * inFlight));
+    c->finishCapacity = inFlight;
+  }
+  if (!c->dLast) HIP_OK(c, hipMalloc((void **)&c->dLast, sizeof(float) * (size_t)moments_len(c)));
+
+  DevParams p;
+  fill_params(c, p);
+  p.seedLo = (uint32_t)seed; p.seedHi = (uint32_t)(seed >> 32);
+  p.slabs = c->dSlabs; p.slabStride = slabStride;
+  p.ppb = (unsigned long long)ppb;
+  p.fates = nullptr;
+  p.counters = c->countersOn ? c->dEventCounters : nullptr;
+  if (c->countersOn) HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 8 * sizeof(unsigned long long), c->stream));
+
+  float traceMs = 0.f;
+  for (int b0 = 0; b0 < nBatches; b0 += (int)inFlight) {
+    const int nb = std::min<int>((int)inFlight, nBatches - b0);
+    p.total = (unsigned long long)ppb * (unsigned long long)nb;
+    p.firstPhoton = firstPhotonId + (unsigned long long)b0 * (unsigned long long)ppb;
+    HIP_OK(c, hipMemsetAsync(c->dSlabs, 0, sizeof(long long) * slabStride * nb, c->stream));  // zero tallies :248-252
+    HIP_OK(c, hipMemsetAsync(c->dCounter, 0, sizeof(unsigned long long), c->stream));
+    HIP_OK(c, hipEventRecord(c->ev0, c->stream));
+    if (launch_trace(c, p, c->countersOn)) return 1;
+    HIP_OK(c, hipEventRecord(c->ev1, c->stream));
+    FinishParams f;
+    f.nx = c->nx; f.ny = c->ny; f.nz = c->nz; f.nBatches = nb; f.xyRegular = c->xyRegular;
+    f.ppb = p.ppb; f.total = p.total; f.slabStride = slabStride;
+    f.slabs = c->dSlabs; f.relArea = c->dRelArea; f.ze = c->dEdges + (c->nx + 1) + (c->ny + 1);
+    f.colVals = c->dColVals; f.scalVals = c->dScalVals; f.moments = c->dMoments; f.last = c->dLast;
+    hipLaunchKernelGGL(finish_columns, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, c->stream, f);
+    hipLaunchKernelGGL(finish_volume, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, c->stream, f);
+    hipLaunchKernelGGL(finish_reduce, dim3(3 + c->nz, nb), dim3(256), 0, c->stream, f);
+    hipLaunchKernelGGL(finish_scalars, dim3((unsigned)((3 + c->nz + 255) / 256)), dim3(256), 0, c->stream, f);
+    HIP_OK(c, hipGetLastError());
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_OK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    traceMs += ms;
+  }
+  c->lastTraceMs = traceMs;
+  if (c->countersOn) {
+    unsigned long long h[8];
+    HIP_OK(c, hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost));
+    c->lastCounters = mcbrat_counters{(int64_t)h[0], (int64_t)h[1], (int64_t)h[2], (int64_t)h[3],
+                                      (int64_t)h[4], (int64_t)h[5], (int64_t)h[6], (int64_t)h[7]};
+  }
+  c->haveLast = true;
+  if (numPhotonsProcessed) *numPhotonsProcessed = ppb * (int64_t)nBatches;
+  c->err = "computeRadiativeTransfer: finished with photons";
+  return 0;
+}
+
+int mcbrat_report_results(mcbrat_ctx *c, float *meanUp, float *meanDown, float *meanAbs, float *fluxUp, float *fluxDown,
+                          float *fluxAbs, float *absorbedProfile, float *volumeAbsorption) {
+  if (!c) return 1;
+  if (!c->haveLast) return fail(c, "reportResults: no batch has been traced yet.");
+  (void)hipSetDevice(c->device);
+  const size_t ncol = (size_t)c->nx * c->ny, nvox = ncol * c->nz;
+  std::vector<float> h((size_t)moments_len(c));
+  HIP_OK(c, hipMemcpy(h.data(), c->dLast, sizeof(float) * h.size(), hipMemcpyDeviceToHost));
+  if (meanUp) *meanUp = h[0];
+  if (meanDown) *meanDown = h[1];
+  if (meanAbs) *meanAbs = h[2];
+  if (fluxUp) std::memcpy(fluxUp, &h[3], sizeof(float) * ncol);
+  if (fluxDown) std::memcpy(fluxDown, &h[3 + ncol], sizeof(float) * ncol);
+  if (fluxAbs) std::memcpy(fluxAbs, &h[3 + 2 * ncol], sizeof(float) * ncol);
+  if (absorbedProfile) std::memcpy(absorbedProfile, &h[3 + 3 * ncol], sizeof(float) * c->nz);
+  if (volumeAbsorption) std::memcpy(volumeAbsorption, &h[3 + 3 * ncol + c->nz], sizeof(float) * nvox);
+  return 0;
+}
+
+int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int64_t n, mcbrat_fate *fates) {
+  if (!c) return 1;
+  (void)hipSetDevice(c->device);
+  if (check_ready(c)) return 1;
+  if (n < 1 || !fates) return fail(c, "trace_fates: nothing to trace.");
+  const size_t ncol = (size_t)c->nx * c->ny, nvox = ncol * c->nz;
+  const size_t slabStride = 2 * ncol + nvox;
+  long long *scratch = nullptr;
+  mcbrat_fate *dF = nullptr;
+  HIP_OK(c, hipMalloc((void **)&scratch, sizeof(long long) * slabStride));
+  HIP_OK(c, hipMalloc((void **)&dF, sizeof(mcbrat_fate) * (size_t)n));
+  HIP_OK(c, hipMemsetAsync(scratch, 0, sizeof(long long) * slabStride, c->stream));
+  HIP_OK(c, hipMemsetAsync(dF, 0xff, sizeof(mcbrat_fate) * (size_t)n, c->stream));
+  HIP_OK(c, hipMemsetAsync(c->dCounter, 0, sizeof(unsigned long long), c->stream));
+  HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 8 * sizeof(unsigned long long), c->stream));
+  DevParams p;
+  fill_params(c, p);
+  p.seedLo = (uint32_t)seed; p.seedHi = (uint32_t)(seed >> 32);
+  p.slabs = scratch; p.slabStride = slabStride;
+  p.ppb = (unsigned long long)n; p.total = (unsigned long long)n; p.firstPhoton = firstPhotonId;
+  p.fates = dF; p.counters = c->dEventCounters;
+  int rc = launch_trace(c, p, true);
+  if (!rc) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(fates, dF, sizeof(mcbrat_fate) * (size_t)n, hipMemcpyDeviceToHost);
+    unsigned long long h[8];
+    if (e == hipSuccess) e = hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(c, std::string("trace_fates: ") + hipGetErrorString(e));
+    else c->lastCounters = mcbrat_counters{(int64_t)h[0], (int64_t)h[1], (int64_t)h[2], (int64_t)h[3],
+                                           (int64_t)h[4], (int64_t)h[5], (int64_t)h[6], (int64_t)h[7]};
+  }
+  (void)hipFree(scratch);
+  (void)hipFree(dF);
+  return rc;
+}
+
+}  // extern "C"

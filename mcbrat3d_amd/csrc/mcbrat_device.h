@@ -1,0 +1,59 @@
+// mcbrat_device.h -- parameter block shared by host launch code and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mcbrat.h"
+
+namespace mcbrat {
+
+constexpr int kWave = 64;                     // CDNA wavefront
+constexpr double kTallyScale = 4294967296.0;  // tallies are signed 64-bit fixed point, 2^-32 resolution
+constexpr double kTallyInv = 1.0 / 4294967296.0;
+
+// States of a lane in the tracing loop.
+enum : int { ST_DEAD = 0, ST_WALK = 1, ST_COLLIDE = 2, ST_SURFACE = 3 };
+
+struct DevParams {
+  // grid (set_grid)
+  int nx, ny, nz, nc;
+  int xyRegular, zRegular;        // new_Integrator :163-181 flags (launch cell lookup only)
+  double x0, y0, z0, xMax, yMax, zMax, Lx, Ly;
+  double zSurf;                   // z0 + spacing(z0): where a reflected photon restarts (:633)
+  double invDX, invDY;            // 1/deltaX, 1/deltaY when xyRegular
+  const double *edges;            // [xe(nx+1) | ye(ny+1) | ze(nz+1)]
+  // optics (set_optics), float copies of the reference's real(8) arrays
+  const float *ext;               // [nvox]
+  const float *cum;               // [nc][nvox] (read only when nc > 1)
+  const float *ssa;               // [nc][nvox]
+  const uint16_t *pfi;            // [nc][nvox] 0-based entry
+  float albedo;
+  // inverse phase-function tables (set_inverse_table)
+  const float *tables;            // all components, concatenated, entry-major
+  int tblOffset[MCBRAT_MAX_COMPONENTS];
+  int tblNSteps[MCBRAT_MAX_COMPONENTS];
+  int tblTotalFloats;
+  // parameters / source
+  int useRR;
+  int lwFlag;                     // LW_flag > 0
+  int srcKind;                    // 0 directional, 1 BB emission
+  float dir0[3];                  // directional: launch direction cosines
+  double zLaunch;                 // directional: launch height
+  int izLaunch;                   // directional: 0-based launch layer
+  const double *voxelCDF;         // emission: running CDF [nvox]
+  double fracAtms;
+  // work
+  unsigned long long *counter;    // next global photon index
+  unsigned long long total;       // photons in this launch
+  unsigned long long ppb;         // photons per batch
+  unsigned long long firstPhoton; // global id of photon index 0
+  uint32_t seedLo, seedHi;
+  long long *slabs;               // per batch: [fluxUp(ncol) | fluxDown(ncol) | volume(nvox)]
+  unsigned long long slabStride;  // in elements
+  int eventThreshold;             // process events when fewer than this many lanes are walking
+  // debug / measurement
+  mcbrat_fate *fates;             // non-null: record per-photon fate (index = photon index)
+  unsigned long long *counters;   // non-null: 8 event counters
+};
+
+}  // namespace mcbrat

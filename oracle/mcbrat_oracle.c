@@ -121,27 +121,35 @@ void orc_philox_init(orc_rng *r, uint64_t seed, uint64_t firstPhoton) {
 
 static void philox_start_photon(orc_rng *r, uint64_t photon) {
   r->photon = photon;
-  r->draw = 0;
+  r->event = 0;
+  r->cachedBlock = 0xffffffffu;
 }
-
-static uint32_t rng_u32(orc_rng *r) {
-  r->ndraws++;
-  if (r->mode == 0) return orc_mt_next_u32(r);
-  if ((r->draw & 3u) == 0) {
-    uint32_t ctr[4] = {r->draw >> 2, 0u, (uint32_t)r->photon, (uint32_t)(r->photon >> 32)};
-    uint32_t key[2] = {(uint32_t)r->seed, (uint32_t)(r->seed >> 32)};
-    orc_philox4x32_10(ctr, key, r->buf);
-  }
-  return r->buf[r->draw++ & 3u];
+static void philox_next_event(orc_rng *r) {
+  r->event++;
+  r->cachedBlock = 0xffffffffu;
 }
 
 /* getRandomDouble / getRandomReal :277-301: u32/(2^32-1) in double, then to
  * float; the closed interval [0,1] (both ends attainable).  The Philox mode
  * multiplies by the reciprocal (what the HIP kernel does) instead of dividing. */
-float orc_random_real(orc_rng *r) {
-  uint32_t u = rng_u32(r);
-  if (r->mode == 0) return (float)((double)u / 4294967295.0);
-  return (float)((double)u * (1.0 / 4294967295.0));
+float orc_random_real(orc_rng *r) { /* sequential (MT) stream */
+  r->ndraws++;
+  return (float)((double)orc_mt_next_u32(r) / 4294967295.0);
+}
+
+/* One uniform for a given role.  MT mode: the next number of the stream (block
+ * and elem are ignored -- call order IS the reference's draw order).  Philox
+ * mode: element `elem` of block `block` of the current event of this photon. */
+static float draw(orc_rng *r, uint32_t block, uint32_t elem) {
+  if (r->mode == 0) return orc_random_real(r);
+  r->ndraws++;
+  if (r->cachedBlock != block) {
+    uint32_t ctr[4] = {r->event, block, (uint32_t)r->photon, (uint32_t)(r->photon >> 32)};
+    uint32_t key[2] = {(uint32_t)r->seed, (uint32_t)(r->seed >> 32)};
+    orc_philox4x32_10(ctr, key, r->buf);
+    r->cachedBlock = block;
+  }
+  return (float)((double)r->buf[elem] * (1.0 / 4294967295.0));
 }
 
 /* ------------------------------------------------------------------------ */
@@ -530,8 +538,8 @@ int orc_emission_weighting(int nx, int ny, int nz, int nc, const double *xe, con
 typedef struct { double x, y, z; float mu, phi; } launch_t;
 
 static void launch_directional(const orc_source *S, orc_rng *R, launch_t *L) { /* :88-96 */
-  L->x = (double)orc_random_real(R);
-  L->y = (double)orc_random_real(R);
+  L->x = (double)draw(R, 0, 0);
+  L->y = (double)draw(R, 0, 1);
   L->z = (double)(1.0f - spacing_f(1.0f));
   L->mu = -fabsf(S->solarMu);
   L->phi = (S->solarAzimuthDeg * acosf(-1.0f)) / 180.0f;
@@ -539,33 +547,36 @@ static void launch_directional(const orc_source *S, orc_rng *R, launch_t *L) { /
 
 static void launch_bbemission(const orc_problem *P, const orc_source *S, orc_rng *R, launch_t *L) { /* :481-516 */
   int nx = P->nx, ny = P->ny, nz = P->nz;
-  float RN = orc_random_real(R);
+  /* Philox slots (event 0): block 0 = [select, r1, r2, r3];
+   * surface: x = r1, y = r2, mu attempts from block 1.., phi = r3;
+   * atmosphere: cdf = r1, z = r2, x = r3, block 1 = [y, phi, mu0, mu1], more mu from block 2.. */
+  float RN = draw(R, 0, 0);
   if ((double)RN > S->fracAtmsPower) { /* surface :484-493 */
-    L->x = (double)orc_random_real(R);
-    L->y = (double)orc_random_real(R);
-    for (;;) {
-      L->mu = sqrtf(orc_random_real(R));
+    L->x = (double)draw(R, 0, 1);
+    L->y = (double)draw(R, 0, 2);
+    for (uint32_t j = 0;; j++) {
+      L->mu = sqrtf(draw(R, 1 + j / 4, j % 4));
       if (fabsf(L->mu) > 2.0f * FLT_MIN) break;
     }
-    L->phi = (orc_random_real(R) * 2.0f) * acosf(-1.0f);
+    L->phi = (draw(R, 0, 3) * 2.0f) * acosf(-1.0f);
     L->z = 0.0;
   } else { /* atmosphere :495-510 */
-    RN = orc_random_real(R);
+    RN = draw(R, 0, 1);
     const double *vw = S->voxelWeights;
     /* levelWeights(k)=vW(nx,ny,k); colWeights(j,k)=vW(nx,j,k) (emissionAndBroadBandWeights.f95:56-57) */
     int ik = find_cdf_index_strided(RN, vw + ((size_t)nx - 1) + (size_t)nx * ((size_t)ny - 1), nz, (int64_t)nx * ny);
     int ij = find_cdf_index_strided(RN, vw + ((size_t)nx - 1) + (size_t)nx * ny * ((size_t)ik - 1), ny, nx);
     int ii = find_cdf_index_strided(RN, vw + (size_t)nx * (((size_t)ij - 1) + (size_t)ny * ((size_t)ik - 1)), nx, 1);
-    L->z = ((double)(ik - 1) * 1.0 / (double)nz) + (double)(orc_random_real(R) / (float)nz);
+    L->z = ((double)(ik - 1) * 1.0 / (double)nz) + (double)(draw(R, 0, 2) / (float)nz);
     if (ik == 1 && L->z == 0.0) L->z = 0.0 + spacing_d(1.0);
     if (ik == nz && L->z > 1.0 - 2.0 * spacing_d(1.0)) L->z = L->z - (2.0 * spacing_d(1.0));
-    L->x = ((double)(ii - 1) * 1.0 / (double)nx) + (double)(orc_random_real(R) * (1.0f / (float)nx));
-    L->y = ((double)(ij - 1) * 1.0 / (double)ny) + (double)(orc_random_real(R) * (1.0f / (float)ny));
-    for (;;) {
-      L->mu = 1.0f - (2.0f * orc_random_real(R));
+    L->x = ((double)(ii - 1) * 1.0 / (double)nx) + (double)(draw(R, 0, 3) * (1.0f / (float)nx));
+    L->y = ((double)(ij - 1) * 1.0 / (double)ny) + (double)(draw(R, 1, 0) * (1.0f / (float)ny));
+    for (uint32_t j = 0;; j++) {
+      L->mu = 1.0f - (2.0f * (j < 2 ? draw(R, 1, 2 + j) : draw(R, 2 + (j - 2) / 4, (j - 2) % 4)));
       if (fabsf(L->mu) > 2.0f * FLT_MIN) break;
     }
-    L->phi = (orc_random_real(R) * 2.0f) * acosf(-1.0f);
+    L->phi = (draw(R, 1, 1) * 2.0f) * acosf(-1.0f);
   }
 }
 
@@ -616,9 +627,9 @@ static float compute_scattering_angle(float u, const float *tbl, int n) { /* :15
 
 static void next_direct(orc_rng *R, float scatteringCosine, float S[3]) { /* :1921-1948 */
   float D = 2.0f, AX = 0.f, AY = 0.f, B;
-  while (D > 1.0f) {
-    AX = 1.0f - 2.0f * orc_random_real(R);
-    AY = 1.0f - 2.0f * orc_random_real(R);
+  for (uint32_t k = 0; D > 1.0f; k++) { /* Philox slots: round k = block 1+k/2, elems 2(k&1), 2(k&1)+1 */
+    AX = 1.0f - 2.0f * draw(R, 1 + (k >> 1), 2 * (k & 1));
+    AY = 1.0f - 2.0f * draw(R, 1 + (k >> 1), 2 * (k & 1) + 1);
     D = AX * AX + AY * AY;
   }
   B = sqrtf((1.0f - scatteringCosine * scatteringCosine) / D);
@@ -730,7 +741,8 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
     int fate = -1;
     float fateWeight = 0.0f;
     for (;;) { /* scatteringLoop :548 */
-      float u = orc_random_real(R);
+      if (R->mode == 1) philox_next_event(R); /* event e: block 0 = [tau, A, B, C] */
+      float u = draw(R, 0, 0);
       float tauToTravel = -logf(u > FLT_MIN ? u : FLT_MIN); /* :554 */
       cnt.legs++;
       double pos[3] = {xPos, yPos, zPos};
@@ -753,11 +765,11 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
         fluxDown[c2] = fluxDown[c2] + photonWeight;
         cnt.surfaceHits++;
         scatteringOrder++;
-        for (;;) {
-          mu = sqrtf(orc_random_real(R));
+        for (uint32_t j = 0;; j++) { /* Philox slots: mu attempt 0 = A, 1 = C, then block 1.. ; phi = B */
+          mu = sqrtf(j == 0 ? draw(R, 0, 1) : j == 1 ? draw(R, 0, 3) : draw(R, 1 + (j - 2) / 4, (j - 2) % 4));
           if (fabsf(mu) > 2.0f * FLT_MIN) break;
         }
-        phi = (2.0f * Pi) * orc_random_real(R);
+        phi = (2.0f * Pi) * draw(R, 0, 2);
         float wBefore = photonWeight;
         photonWeight = (float)((double)photonWeight * albedo); /* :673 */
         if (photonWeight <= FLT_MIN) { cnt.surfaceAbsorbed++; fate = 1; fateWeight = wBefore; break; }
@@ -794,7 +806,7 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
         double tbl[ORC_MAX_COMPONENTS + 1];
         tbl[0] = 0.0;
         for (int c = 1; c <= nc; c++) tbl[c] = P->cumExt[IDX4(P, xIndex, yIndex, zIndex, c)];
-        int component = orc_find_index_mixed(orc_random_real(R), tbl, nc + 1, 0); /* :759-760 */
+        int component = orc_find_index_mixed(draw(R, 0, 1), tbl, nc + 1, 0); /* slot A */ /* :759-760 */
         if (component < 1) component = 1;
         if (component > nc) component = nc;
         float ssa = (float)P->ssa[IDX4(P, xIndex, yIndex, zIndex, component)]; /* :764 */
@@ -807,14 +819,14 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
           cnt.absorbEvents++;
         }
         if (P->useRussianRoulette && photonWeight < RussianRouletteW / 2.0f) { /* :805-811 */
-          if (orc_random_real(R) >= photonWeight / RussianRouletteW) { photonWeight = 0.0f; cnt.rouletteKills++; }
+          if (draw(R, 0, 2) >= photonWeight / RussianRouletteW) /* slot B */ { photonWeight = 0.0f; cnt.rouletteKills++; }
           else { photonWeight = RussianRouletteW; cnt.rouletteSurvivals++; }
         }
         if (photonWeight <= FLT_MIN) { fate = 2; break; } /* :812 */
         int pfi = P->pfIndex[IDX4(P, xIndex, yIndex, zIndex, component)]; /* :816 */
         int ns = P->invNSteps[component - 1];
         const float *tblf = P->invTables + P->invOffset[component - 1] + (size_t)(pfi - 1) * ns;
-        float scatteringAngle = compute_scattering_angle(orc_random_real(R), tblf, ns);
+        float scatteringAngle = compute_scattering_angle(draw(R, 0, 3), tblf, ns); /* slot C */
         next_direct(R, cosf(scatteringAngle), dir); /* :819 */
       }
     }

@@ -55,9 +55,13 @@ typedef struct {
 } orc_source;
 
 /* Random numbers.  mode 0: MT19937 exactly as src/RandomNumbersForMC.f95
- * (one sequential stream, state carried across calls).  mode 1: Philox4x32-10
- * keyed by seed, counter = (draw/4, 0, photon id) -- the generator the
- * BASELINE north_star substitutes; draw ORDER per photon is the reference's. */
+ * (one sequential stream, state carried across calls; the draw ORDER is the
+ * reference's).  mode 1: Philox4x32-10, the counter-based generator the
+ * BASELINE north_star substitutes.  key = seed, counter = (event, block,
+ * photon id lo, photon id hi).  event 0 is the launch, event e >= 1 the e-th
+ * leg; each role has a fixed slot (see draw() call sites in mcbrat_oracle.c and
+ * the same table in mcbrat3d_amd/csrc/mcbrat_kernels.hip), so the HIP kernel and
+ * this oracle consume identical uniforms for identical roles. */
 typedef struct {
   int32_t mode;
   int32_t mti;
@@ -66,7 +70,8 @@ typedef struct {
   uint64_t firstPhoton;              /* philox: id of photon 0 of this batch  */
   /* scratch */
   uint64_t photon;
-  uint32_t draw;
+  uint32_t event;
+  uint32_t cachedBlock;              /* block index held in buf, or 0xffffffff */
   uint32_t buf[4];
   uint64_t ndraws;
 } orc_rng;

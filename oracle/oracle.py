@@ -44,7 +44,7 @@ class OrcRng(C.Structure):
     _fields_ = [
         ("mode", C.c_int32), ("mti", C.c_int32), ("mt", C.c_uint32 * 624),
         ("seed", C.c_uint64), ("firstPhoton", C.c_uint64),
-        ("photon", C.c_uint64), ("draw", C.c_uint32), ("buf", C.c_uint32 * 4),
+        ("photon", C.c_uint64), ("event", C.c_uint32), ("cachedBlock", C.c_uint32), ("buf", C.c_uint32 * 4),
         ("ndraws", C.c_uint64),
     ]
 

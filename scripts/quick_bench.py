@@ -1,0 +1,50 @@
+"""Development timing loop (not the judged bench): step cloud / landsat-like, sweeps of tuning knobs."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from tests import cases  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="step")
+    ap.add_argument("--ppb", type=int, default=100000)
+    ap.add_argument("--batches", type=int, default=100)
+    ap.add_argument("--thr", type=int, nargs="*", default=[40])
+    ap.add_argument("--bpc", type=int, nargs="*", default=[0])
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.step_cloud(0.99) if a.case == "step" else cases.landsat_like()
+    mu0, phi0 = (1.0, 0.0) if a.case == "step" else (0.5, 30.0)
+    t0 = time.time()
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=10001)
+    photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
+    print("setup %.2fs" % (time.time() - t0), flush=True)
+    for bpc in a.bpc:
+        for thr in a.thr:
+            integ.setTuning(blocksPerCU=bpc, eventThreshold=thr)
+            rates = []
+            for r in range(a.reps):
+                rng = new_RandomNumberSequence(1234 + r)
+                integ.resetMoments()
+                t = time.time()
+                n = integ.computeRadiativeTransfer(dom, rng, photons, a.ppb, a.batches)
+                dt = time.time() - t
+                rates.append((n / dt, n / (integ.lastTraceMs() * 1e-3)))
+            res = integ.reportResults()
+            print("case=%s bpc=%d thr=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
+                a.case, bpc, thr, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
+                res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -115,3 +115,16 @@ def oracle_problem(case, nsteps=10001, use_russian_roulette=True, lw_flag=-1.0):
     tables = [np.stack([O.inverse_table_legendre(c, nsteps) for c in comp["legendre"]]) for comp in case["components"]]
     return O.Problem(case["xe"], case["ye"], case["ze"], tot, cum, ssa, pfi, case["albedo"], tables,
                      use_russian_roulette=use_russian_roulette, lw_flag=lw_flag)
+
+
+def product_domain(case):
+    """Hand a case to the PRODUCT through its reference-shaped host interface."""
+    import mcbrat3d_amd as M
+    dom = M.new_Domain(case["xe"], case["ye"], case["ze"], temps=case.get("temps"),
+                       surfaceAlbedo=case["albedo"], lambda_um=case.get("lambda_um", 0.0))
+    for i, comp in enumerate(case["components"]):
+        table = M.new_PhaseFunctionTable([M.new_PhaseFunction(c) for c in comp["legendre"]])
+        dom.addOpticalComponent("component%d" % (i + 1), comp["ext"], comp["ssa"], comp["pfIndex"], table,
+                                zLevelBase=comp.get("zLevelBase", 1))
+    dom.getOpticalPropertiesByComponent()
+    return dom
