@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- photons/sec of the photon-tracing hot path on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete job of the workload on every rank: the I3RC step cloud
+(BASELINE.json configs[1]: 32x1x32, tau 2|18, omega0 0.99, HG g 0.85, mu0 1) traced with
+1e7 photons per GPU as 100 batches of 1e5 (computeRadiativeTransfer + reportResults +
+batch moments on the device), followed by the all-reduce of the moment arrays over RCCL
+(the reference's sumAcrossProcesses).  Weak scaling: every rank traces its own 1e7
+photons per step (disjoint photon-id ranges of one Philox key).  Inputs (grids, tables)
+are resident in HBM before the timed region; photons are generated on the GPU.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- algorithmic bytes of the tracing kernel / its HIP-event duration vs HBM peak
+  cpu_baseline -- the CPU oracle (a port of the reference loop, pinned to the reference's
+                  own outputs) timed on this box's host cores on a bounded photon sample
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from tests import cases  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+WORKLOADS = {
+    "i3rcStepCloud": dict(make=lambda: cases.step_cloud(ssa=0.99), mu0=1.0, phi0=0.0, ppb=100000, batches=100),
+    "landsatLike128": dict(make=lambda: cases.landsat_like(), mu0=0.5, phi0=30.0, ppb=1000000, batches=10),
+}
+
+
+def algorithmic_bytes_per_photon(c, n, nc):
+    """B = 4 N_cross + (4 nc + 14) N_coll + 16 N_abs + 8 N_exit (per photon)."""
+    return (4.0 * c["crossings"] + (4.0 * nc + 14.0) * c["collisions"] + 16.0 * c["absorbEvents"] +
+            8.0 * (c["topExits"] + c["surfaceHits"])) / n
+
+
+def _cpu_worker(args):
+    """cpu_baseline leg: the ORACLE, one process per core, MT stream seeded (/iseed, proc, 0/)."""
+    name, n, proc = args
+    from oracle import oracle as O
+    w = WORKLOADS[name]
+    P = cases.oracle_problem(w["make"]())
+    t = time.time()
+    res = O.compute_radiative_transfer(P, O.solar_source(w["mu0"], w["phi0"]), O.mt_rng([10, proc, 0]), n)
+    return time.time() - t, n, res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"], res["fluxUp"], \
+        res["fluxDown"], res["fluxAbsorbed"], res["counters"]
+
+
+def cpu_baseline(name, photons_per_core, max_cores):
+    from oracle import oracle as O
+    O.build()
+    cores = max(1, min(max_cores, len(os.sched_getaffinity(0))))
+    t = time.time()
+    with mp.get_context("spawn").Pool(cores) as pool:
+        out = pool.map(_cpu_worker, [(name, photons_per_core, p + 1) for p in range(cores)])
+    wall = time.time() - t
+    total = sum(o[1] for o in out)
+    busiest = max(o[0] for o in out)
+    batches = [(o[1], np.array([o[2], o[3], o[4]])) for o in out]
+    cols = [(o[1], np.concatenate([o[5], o[6], o[7]])) for o in out]
+    counters = {k: sum(o[8][k] for o in out) for k in out[0][8]}
+    return dict(value=total / busiest, unit="photons/s", cores=cores, kind="port",
+                sample="%d photons/core x %d cores of the same workload, oracle in MT mode (%.1f s wall)" % (
+                    photons_per_core, cores, wall)), batches, cols, counters, total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="i3rcStepCloud", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-photons-per-core", type=int, default=1500000)
+    ap.add_argument("--cpu-cores", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the photon-tracing path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd import driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+
+    w = WORKLOADS[a.workload]
+    case = w["make"]()
+    dom = cases.product_domain(case)
+    nx, ny, nz = dom.numX, dom.numY, dom.numZ
+    nc = len(dom.components)
+    integ = M.new_Integrator(dom, device=local_rank)
+    integ.specifyParameters(minInverseTableSize=10001, useRayTracing=True, useRussianRoulette=True)
+    photons = M.new_PhotonStream(w["mu0"], w["phi0"], numberOfPhotons=10 ** 15)
+    ppb, nb = w["ppb"], w["batches"]
+    per_step = ppb * nb
+    moments = torch.zeros(8 + 2 * integ.momentsLength(), dtype=torch.float64, device=dev)
+    integ.bindMoments(moments.data_ptr())
+    rng = new_RandomNumberSequence(10)
+
+    def step(i):
+        # rank r traces photon ids [ (i*world + r) * per_step, +per_step ): disjoint over ranks and steps
+        rng.nextPhotonId = (i * world + rank) * per_step
+        photons.currentPhoton = 1
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, rng, photons, ppb, nb)
+        if dist is not None:
+            dist.all_reduce(moments, op=dist.ReduceOp.SUM)  # sumAcrossProcesses, monteCarloDriver.f95:1151-1166
+            torch.cuda.synchronize()
+        return integ.lastTraceMs()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for i in range(a.steps):
+        kernel_ms += step(a.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        # the moment arrays now hold the last step: world * per_step photons, reduced over ranks
+        stats = driver.statistics(driver.unpack_moments(moments.cpu().numpy(), nx, ny, nz))
+        # untimed: event counters (instrumented kernel) on one step's worth of photons
+        integ.bindMoments(0)
+        integ.resetMoments()
+        integ.enableCounters(True)
+        rng.nextPhotonId = 0
+        photons.currentPhoton = 1
+        integ.computeRadiativeTransfer(dom, rng, photons, ppb, nb)
+        cnt = integ.counters()
+        integ.enableCounters(False)
+        bpp = algorithmic_bytes_per_photon(cnt, per_step, nc)
+        launch_ms = kernel_ms / a.steps
+        achieved = bpp * per_step / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get(a.workload, {}).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "photons/sec", "value": world * per_step * a.steps / elapsed, "unit": "photons/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64",
+            "data": "synthetic",
+            "config": {"workload": "%s %dx%dx%d, %d photons/GPU/step as %d batches x %d, omega0=0.99 HG g=0.85 mu0=%g"
+                       % (a.workload, nx, ny, nz, per_step, nb, ppb, w["mu0"]),
+                       "photons_per_step_per_gpu": per_step, "parallelism": "photon batches sharded over %d GPU(s)" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_photon": bpp, "kernel": "trace_kernel", "kernel_ms_per_launch": launch_ms,
+                         "events_per_photon": {k: v / per_step for k, v in cnt.items()},
+                         "note": "working set is cache resident; the path is latency/VALU bound (DESIGN.md)"},
+        }
+        if not a.no_cpu_baseline:
+            cb, batches, cols, ccnt, ctot = cpu_baseline(a.workload, a.cpu_photons_per_core, a.cpu_cores)
+            out["cpu_baseline"] = cb
+            # flux error vs the CPU reference path, in units of the combined Monte Carlo sigma
+            from oracle import oracle as O
+            m_ref, e_ref = O.batch_statistics(batches)
+            c_ref, ce_ref = O.batch_statistics(cols)
+            g = np.array([stats["meanFluxUp"], stats["meanFluxDown"], stats["meanFluxAbsorbed"]])
+            ge = np.array([stats["meanFluxUp_StdErr"], stats["meanFluxDown_StdErr"], stats["meanFluxAbsorbed_StdErr"]])
+            z = (g - m_ref) / np.sqrt(ge ** 2 + e_ref ** 2 + 1e-30)
+            gc = np.concatenate([stats[k].T.reshape(-1) for k in ("fluxUp", "fluxDown", "fluxAbsorbed")])
+            gce = np.concatenate([stats[k + "_StdErr"].T.reshape(-1) for k in ("fluxUp", "fluxDown", "fluxAbsorbed")])
+            zc = (gc - c_ref) / np.sqrt(gce ** 2 + ce_ref ** 2 + 1e-30)
+            out["parity"] = {"max_abs_z_domain_mean": float(np.max(np.abs(z))),
+                             "max_abs_z_column": float(np.max(np.abs(zc))), "mean_z_column": float(np.mean(zc)),
+                             "gpu_means": [float(x) for x in g], "cpu_means": [float(x) for x in m_ref],
+                             "cpu_events_per_photon": {k: v / ctot for k, v in ccnt.items() if k != "draws"}}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
