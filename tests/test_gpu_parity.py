@@ -70,3 +70,73 @@ def test_step_cloud_batch_matches_oracle(M):
     assert np.allclose(got["absorbedProfile"], ref["absorbedProfile"], rtol=5e-3, atol=1e-6)
     # energy closure, SW albedo 0 (monteCarloRadiativeTransfer.f95:221-223)
     assert abs(got["meanFluxUp"] + got["meanFluxDown"] + got["meanFluxAbsorbed"] - 1.0) < 3.0 / np.sqrt(n)
+
+
+@pytest.fixture(scope="module")
+def landsat():
+    return cases.landsat_like()
+
+
+def test_landsat_like_fates_and_batch(M, landsat):
+    """128x128x64, irregular x/y/z grid, two components (multi-entry HG cloud table that does
+    not fit LDS + 1-D Rayleigh), mu0 = 0.5, phi0 = 30 deg: per-photon and per-batch parity."""
+    from oracle import oracle as O
+    n = 40000
+    dom, integ, photons, rng = _setup(M, landsat, 0.5, 30.0)
+    got = integ.traceFates(dom, rng, photons, n)
+    P = cases.oracle_problem(landsat)
+    assert P.grid_flags()[:2] == (False, False)
+    ref = O.compute_rt(P, O.solar_source(0.5, 30.0), O.philox_rng(SEED, 0), n, want_fates=True)
+    rf = ref["fates"]
+    same = (got["fate"] == rf["fate"]) & (got["ix"] == rf["ix"]) & (got["iy"] == rf["iy"]) & \
+        (got["nScatter"] == rf["nScatter"]) & (np.abs(got["weight"] - rf["weight"]) <= 1e-6)
+    assert same.mean() > 0.99, "only %.4f of photon histories identical" % same.mean()
+    done = integ.computeRadiativeTransfer(dom, rng, photons, n)
+    res = integ.reportResults()
+    norm = O.normalize(P, n, ref)
+    mu, md, ma, prof = O.report_means(P, norm)
+    assert done == n
+    for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
+        assert abs(g - r) < 5e-3 * max(r, 0.05), (g, r)
+    assert np.allclose(res["absorbedProfile"], prof, rtol=0.03, atol=2e-5 * np.max(prof) + 1e-9)
+    # column fluxes: each column sees ~2.4 photons, so compare the exact integer-like sums
+    up_ref = norm["fluxUp"].reshape(128, 128).T
+    assert abs(res["fluxUp"].sum() - up_ref.sum()) < 5e-3 * up_ref.sum()
+
+
+def test_thermal_emission_matches_oracle(M):
+    """LW path: emission_weighting -> BBEmission photon stream -> computeRT with LW_flag > 0
+    (launch from the running voxel CDF or the surface, emission tallied as negative
+    absorption, Lambertian surface albedo 0.1)."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    from oracle import oracle as O
+    n = 60000
+    case = cases.homog_lw(n=20)
+    case["temps"] = case["temps"] + np.linspace(-15, 15, 20)[None, None, :]
+    dom = cases.product_domain(case)
+    w = M.new_Weights(20, 20, 20)
+    M.emission_weighting(dom, w, case["sfc_temp"])
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True, LW_flag=1.0)
+    photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 9)
+    got = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+
+    P = cases.oracle_problem(case, nsteps=9001, lw_flag=1.0)
+    vw, frac, _ = O.emission_weighting(P, case["temps"].transpose(2, 1, 0).reshape(-1), case["lambda_um"], case["sfc_temp"])
+    assert np.array_equal(vw, w.voxelWeights) and frac == w.fracAtmsPower
+    src = O.EmissionSource(vw, frac)
+    ref = O.compute_rt(P, src, O.philox_rng(SEED, 0), n, want_fates=True)
+    rf = ref["fates"]
+    same = (got["fate"] == rf["fate"]) & (got["ix"] == rf["ix"]) & (got["iy"] == rf["iy"]) & \
+        (got["nScatter"] == rf["nScatter"]) & (np.abs(got["weight"] - rf["weight"]) <= 1e-6)
+    assert same.mean() > 0.995, "only %.4f of photon histories identical" % same.mean()
+
+    rng = new_RandomNumberSequence(SEED)
+    assert integ.computeRadiativeTransfer(dom, rng, photons, n) == n
+    res = integ.reportResults()
+    norm = O.normalize(P, n, ref)
+    mu, md, ma, prof = O.report_means(P, norm)
+    for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
+        assert abs(g - r) < 4e-3 * max(abs(r), 0.05), (g, r)
+    assert ma < 0  # the layer emits more than it absorbs
+    assert np.allclose(res["absorbedProfile"], prof, rtol=0.05, atol=0.02 * np.max(np.abs(prof)))
