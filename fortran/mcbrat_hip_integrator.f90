@@ -1,0 +1,289 @@
+! mcbrat_hip_integrator.f90 -- ISO_C_BINDING shim over include/mcbrat.h.
+!
+! Stands where Integrators/monteCarloRadiativeTransfer.f95 stands: the same public names
+! (integrator, new_Integrator, specifyParameters, computeRadiativeTransfer, reportResults,
+! finalize_Integrator; reference public list :121-123), with the photon loop computeRT
+! (:393-841) running in the HIP library.  The domain is handed over as the raw arrays that
+! computeRT itself pulls out of type(domain) with getInfo_Domain (:434-443); INTEGRATION.md
+! shows the three-line wrapper that does that inside the reference tree.
+!
+! Status convention: each routine returns `ierr` (0 = success) and leaves the text in
+! lastMessage(); the in-tree wrapper maps it to setStateToFailure / setStateToCompleteSuccess.
+module mcbrat_hip_integrator
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+
+  type integrator
+    private
+    type(c_ptr) :: ctx = c_null_ptr
+    integer     :: numX = 0, numY = 0, numZ = 0
+    logical     :: readyToCompute = .false.
+  end type integrator
+
+  public :: integrator, new_Integrator, isReady_Integrator, finalize_Integrator, &
+            setOpticalProperties, setInverseTable, setSolarSource, setEmissionSource, &
+            specifyParameters, computeRadiativeTransfer, reportResults, &
+            resetMoments, getMoments, momentsLength, lastMessage, &
+            inverseTableLegendre, lastTraceMilliseconds
+
+  interface
+    function mcbrat_create(device) bind(C, name="mcbrat_create") result(ctx)
+      import :: c_ptr, c_int
+      integer(c_int), value :: device
+      type(c_ptr) :: ctx
+    end function
+    subroutine mcbrat_destroy(ctx) bind(C, name="mcbrat_destroy")
+      import :: c_ptr
+      type(c_ptr), value :: ctx
+    end subroutine
+    function mcbrat_last_error(ctx) bind(C, name="mcbrat_last_error") result(msg)
+      import :: c_ptr
+      type(c_ptr), value :: ctx
+      type(c_ptr) :: msg
+    end function
+    function mcbrat_set_grid(ctx, nx, ny, nz, xe, ye, ze) bind(C, name="mcbrat_set_grid") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: nx, ny, nz
+      real(c_double), intent(in) :: xe(*), ye(*), ze(*)
+      integer(c_int) :: rc
+    end function
+    function mcbrat_set_optics(ctx, nc, totalExt, cumExt, ssa, pfi, albedo) bind(C, name="mcbrat_set_optics") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: nc
+      real(c_double), intent(in) :: totalExt(*), cumExt(*), ssa(*)
+      integer(c_int32_t), intent(in) :: pfi(*)
+      real(c_double), value :: albedo
+      integer(c_int) :: rc
+    end function
+    function mcbrat_set_inverse_table(ctx, comp, nSteps, nEntries, table) bind(C, name="mcbrat_set_inverse_table") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_float
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: comp, nSteps, nEntries
+      real(c_float), intent(in) :: table(*)
+      integer(c_int) :: rc
+    end function
+    function mcbrat_specify_parameters(ctx, rayTracing, roulette, lwFlag) bind(C, name="mcbrat_specify_parameters") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_float
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: rayTracing, roulette
+      real(c_float), value :: lwFlag
+      integer(c_int) :: rc
+    end function
+    function mcbrat_set_source_solar(ctx, mu, azimuth) bind(C, name="mcbrat_set_source_solar") result(rc)
+      import :: c_ptr, c_int, c_float
+      type(c_ptr), value :: ctx
+      real(c_float), value :: mu, azimuth
+      integer(c_int) :: rc
+    end function
+    function mcbrat_set_source_emission(ctx, voxelWeights, fracAtms) bind(C, name="mcbrat_set_source_emission") result(rc)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(in) :: voxelWeights(*)
+      real(c_double), value :: fracAtms
+      integer(c_int) :: rc
+    end function
+    function mcbrat_compute_radiative_transfer(ctx, seed, firstId, ppb, nBatches, nDone) &
+        bind(C, name="mcbrat_compute_radiative_transfer") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: seed, firstId, ppb
+      integer(c_int32_t), value :: nBatches
+      integer(c_int64_t), intent(out) :: nDone
+      integer(c_int) :: rc
+    end function
+    function mcbrat_report_results(ctx, mUp, mDown, mAbs, fUp, fDown, fAbs, prof, vol) &
+        bind(C, name="mcbrat_report_results") result(rc)
+      import :: c_ptr, c_int, c_float
+      type(c_ptr), value :: ctx
+      real(c_float), intent(out) :: mUp, mDown, mAbs
+      real(c_float), intent(out) :: fUp(*), fDown(*), fAbs(*), prof(*), vol(*)
+      integer(c_int) :: rc
+    end function
+    function mcbrat_moments_length(ctx) bind(C, name="mcbrat_moments_length") result(n)
+      import :: c_ptr, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t) :: n
+    end function
+    function mcbrat_reset_moments(ctx) bind(C, name="mcbrat_reset_moments") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
+      integer(c_int) :: rc
+    end function
+    function mcbrat_get_moments(ctx, buf) bind(C, name="mcbrat_get_moments") result(rc)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(out) :: buf(*)
+      integer(c_int) :: rc
+    end function
+    function mcbrat_last_trace_ms(ctx) bind(C, name="mcbrat_last_trace_ms") result(ms)
+      import :: c_ptr, c_float
+      type(c_ptr), value :: ctx
+      real(c_float) :: ms
+    end function
+    function mcbrat_inverse_table_legendre(nCoef, coef, nSteps, table) bind(C, name="mcbrat_inverse_table_legendre") result(rc)
+      import :: c_int, c_int32_t, c_float
+      integer(c_int32_t), value :: nCoef, nSteps
+      real(c_float), intent(in) :: coef(*)
+      real(c_float), intent(out) :: table(*)
+      integer(c_int) :: rc
+    end function
+  end interface
+
+contains
+  !------------------------------------------------------------------------------------------
+  function lastMessage(this) result(msg)
+    type(integrator), intent(in) :: this
+    character(len=256) :: msg
+    character(kind=c_char), pointer :: chars(:)
+    type(c_ptr) :: p
+    integer :: i
+    msg = ""
+    p = mcbrat_last_error(this%ctx)
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, chars, (/ 256 /))
+    do i = 1, 256
+      if (chars(i) == c_null_char) exit
+      msg(i:i) = chars(i)
+    end do
+  end function lastMessage
+  !------------------------------------------------------------------------------------------
+  ! new_Integrator(atmosphere, status): here from the cell edges getInfo_Domain returns
+  function new_Integrator(xPosition, yPosition, zPosition, device, ierr) result(new)
+    real(8), dimension(:), intent(in) :: xPosition, yPosition, zPosition
+    integer,               intent(in) :: device
+    integer,               intent(out):: ierr
+    type(integrator) :: new
+    new%ctx = mcbrat_create(int(device, c_int))
+    if (.not. c_associated(new%ctx)) then
+      ierr = 1   ! "new_Integrator: no usable HIP device" -- there is no CPU fallback
+      return
+    end if
+    new%numX = size(xPosition) - 1; new%numY = size(yPosition) - 1; new%numZ = size(zPosition) - 1
+    ierr = mcbrat_set_grid(new%ctx, int(new%numX, c_int32_t), int(new%numY, c_int32_t), int(new%numZ, c_int32_t), &
+                           xPosition, yPosition, zPosition)
+    new%readyToCompute = (ierr == 0)
+  end function new_Integrator
+  !------------------------------------------------------------------------------------------
+  logical function isReady_Integrator(this)
+    type(integrator), intent(in) :: this
+    isReady_Integrator = this%readyToCompute
+  end function isReady_Integrator
+  !------------------------------------------------------------------------------------------
+  subroutine finalize_Integrator(this)
+    type(integrator), intent(inout) :: this
+    if (c_associated(this%ctx)) call mcbrat_destroy(this%ctx)
+    this%ctx = c_null_ptr
+    this%readyToCompute = .false.
+  end subroutine finalize_Integrator
+  !------------------------------------------------------------------------------------------
+  ! What computeRT pulls from the domain (getInfo_Domain :441-443)
+  subroutine setOpticalProperties(this, totalExt, cumExt, ssa, phaseFuncI, albedo, ierr)
+    type(integrator),            intent(inout) :: this
+    real(8), dimension(:,:,:),   intent(in)    :: totalExt
+    real(8), dimension(:,:,:,:), intent(in)    :: cumExt, ssa
+    integer, dimension(:,:,:,:), intent(in)    :: phaseFuncI
+    real(8),                     intent(in)    :: albedo
+    integer,                     intent(out)   :: ierr
+    ierr = mcbrat_set_optics(this%ctx, int(size(cumExt, 4), c_int32_t), totalExt, cumExt, ssa, phaseFuncI, albedo)
+  end subroutine setOpticalProperties
+  !------------------------------------------------------------------------------------------
+  subroutine setInverseTable(this, component, values, ierr)   ! inversePhaseFuncs(component)%values
+    type(integrator),     intent(inout) :: this
+    integer,              intent(in)    :: component
+    real, dimension(:,:), intent(in)    :: values
+    integer,              intent(out)   :: ierr
+    ierr = mcbrat_set_inverse_table(this%ctx, int(component, c_int32_t), int(size(values, 1), c_int32_t), &
+                                    int(size(values, 2), c_int32_t), values)
+  end subroutine setInverseTable
+  !------------------------------------------------------------------------------------------
+  subroutine setSolarSource(this, solarMu, solarAzimuth, ierr)   ! new_PhotonStream, Directional
+    type(integrator), intent(inout) :: this
+    real,             intent(in)    :: solarMu, solarAzimuth
+    integer,          intent(out)   :: ierr
+    ierr = mcbrat_set_source_solar(this%ctx, solarMu, solarAzimuth)
+  end subroutine setSolarSource
+  !------------------------------------------------------------------------------------------
+  subroutine setEmissionSource(this, voxelWeights, fracAtmsPower, ierr)   ! new_PhotonStream, BBEmission
+    type(integrator),          intent(inout) :: this
+    real(8), dimension(:,:,:), intent(in)    :: voxelWeights
+    real(8),                   intent(in)    :: fracAtmsPower
+    integer,                   intent(out)   :: ierr
+    ierr = mcbrat_set_source_emission(this%ctx, voxelWeights, fracAtmsPower)
+  end subroutine setEmissionSource
+  !------------------------------------------------------------------------------------------
+  ! specifyParameters: the keywords the driver passes (monteCarloDriver.f95:540-572)
+  subroutine specifyParameters(this, useRayTracing, useRussianRoulette, LW_flag, ierr)
+    type(integrator), intent(inout) :: this
+    logical,          intent(in)    :: useRayTracing, useRussianRoulette
+    real,             intent(in)    :: LW_flag
+    integer,          intent(out)   :: ierr
+    ierr = mcbrat_specify_parameters(this%ctx, merge(1_c_int32_t, 0_c_int32_t, useRayTracing), &
+                                     merge(1_c_int32_t, 0_c_int32_t, useRussianRoulette), LW_flag)
+  end subroutine specifyParameters
+  !------------------------------------------------------------------------------------------
+  ! computeRadiativeTransfer(thisIntegrator, thisDomain, randomNumbers, incomingPhotons,
+  !                          numPhotonsPerBatch, numPhotonsProcessed, status)
+  ! randomNumbers -> (seed, firstPhotonId): counter-based generator keyed by photon id.
+  subroutine computeRadiativeTransfer(this, seed, firstPhotonId, numPhotonsPerBatch, numBatches, &
+                                      numPhotonsProcessed, ierr)
+    type(integrator), intent(inout) :: this
+    integer(8),       intent(in)    :: seed, firstPhotonId, numPhotonsPerBatch
+    integer,          intent(in)    :: numBatches
+    integer(8),       intent(out)   :: numPhotonsProcessed
+    integer,          intent(out)   :: ierr
+    if (.not. this%readyToCompute) then
+      ierr = 1; numPhotonsProcessed = 0
+      return
+    end if
+    ierr = mcbrat_compute_radiative_transfer(this%ctx, seed, firstPhotonId, numPhotonsPerBatch, &
+                                             int(numBatches, c_int32_t), numPhotonsProcessed)
+  end subroutine computeRadiativeTransfer
+  !------------------------------------------------------------------------------------------
+  subroutine reportResults(this, meanFluxUp, meanFluxDown, meanFluxAbsorbed, fluxUp, fluxDown, fluxAbsorbed, &
+                           absorbedProfile, volumeAbsorption, ierr)
+    type(integrator),         intent(in)  :: this
+    real,                     intent(out) :: meanFluxUp, meanFluxDown, meanFluxAbsorbed
+    real, dimension(:,:),     intent(out) :: fluxUp, fluxDown, fluxAbsorbed
+    real, dimension(:),       intent(out) :: absorbedProfile
+    real, dimension(:,:,:),   intent(out) :: volumeAbsorption
+    integer,                  intent(out) :: ierr
+    if (any(shape(fluxUp) /= (/ this%numX, this%numY /)) .or. size(absorbedProfile) /= this%numZ .or. &
+        any(shape(volumeAbsorption) /= (/ this%numX, this%numY, this%numZ /))) then
+      ierr = 2   ! "reportResults: ... array is the wrong size"
+      return
+    end if
+    ierr = mcbrat_report_results(this%ctx, meanFluxUp, meanFluxDown, meanFluxAbsorbed, fluxUp, fluxDown, fluxAbsorbed, &
+                                 absorbedProfile, volumeAbsorption)
+  end subroutine reportResults
+  !------------------------------------------------------------------------------------------
+  integer(8) function momentsLength(this)
+    type(integrator), intent(in) :: this
+    momentsLength = mcbrat_moments_length(this%ctx)
+  end function momentsLength
+  subroutine resetMoments(this, ierr)
+    type(integrator), intent(inout) :: this
+    integer, intent(out) :: ierr
+    ierr = mcbrat_reset_moments(this%ctx)
+  end subroutine resetMoments
+  subroutine getMoments(this, buffer, ierr)   ! header(8) + S1(M) + S2(M), see include/mcbrat.h
+    type(integrator), intent(inout) :: this
+    real(8), dimension(:), intent(out) :: buffer
+    integer, intent(out) :: ierr
+    ierr = mcbrat_get_moments(this%ctx, buffer)
+  end subroutine getMoments
+  real function lastTraceMilliseconds(this)
+    type(integrator), intent(in) :: this
+    lastTraceMilliseconds = mcbrat_last_trace_ms(this%ctx)
+  end function lastTraceMilliseconds
+  !------------------------------------------------------------------------------------------
+  subroutine inverseTableLegendre(coefficients, table, ierr)   ! computeInversePhaseFunction
+    real, dimension(:), intent(in)  :: coefficients
+    real, dimension(:), intent(out) :: table
+    integer,            intent(out) :: ierr
+    ierr = mcbrat_inverse_table_legendre(int(size(coefficients), c_int32_t), coefficients, &
+                                         int(size(table), c_int32_t), table)
+  end subroutine inverseTableLegendre
+end module mcbrat_hip_integrator

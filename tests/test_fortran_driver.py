@@ -1,0 +1,81 @@
+"""The Fortran driver surface (reference namelists -> ISO_C_BINDING shim -> HIP library) must
+give the same numbers as the Python host layer for the same seed: both are thin layers over
+one C ABI and photon ids carry the random numbers."""
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FDIR = os.path.join(ROOT, "fortran")
+
+
+def _build():
+    if shutil.which("amdflang") is None and not os.path.exists(os.path.join(FDIR, "mcbrat_driver")):
+        pytest.skip("no Fortran compiler on this box and no prebuilt driver")
+    if shutil.which("amdflang") is not None:
+        subprocess.check_call(["make", "-C", FDIR], stdout=subprocess.DEVNULL)
+    return os.path.join(FDIR, "mcbrat_driver")
+
+
+def test_shim_compiles_and_declares_the_reference_names():
+    """No GPU needed: the shim builds and keeps the integrator's public names (:121-123)."""
+    if shutil.which("amdflang") is None:
+        pytest.skip("no Fortran compiler")
+    from mcbrat3d_amd import build
+    build.build()
+    _build()
+    src = open(os.path.join(FDIR, "mcbrat_hip_integrator.f90")).read()
+    for name in ("integrator", "new_Integrator", "isReady_Integrator", "finalize_Integrator", "specifyParameters",
+                 "computeRadiativeTransfer", "reportResults"):
+        assert re.search(r"public ::[^!]*\b%s\b" % name, src.replace("&\n", " ")), name
+
+
+@pytest.mark.gpu
+def test_fortran_driver_matches_python_host(tmp_path):
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd import driver, flatdomain
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    exe = _build()
+    ppb, nb = 50000, 8
+    results = {}
+    # (1) built-in step cloud, (2) the same domain through a flat file written by the Python layer
+    case = cases.step_cloud(0.99)
+    dom = cases.product_domain(case)
+    flat = flatdomain.write_flat_domain(str(tmp_path / "step.flat"), dom)
+    for tag, domfile in (("builtin", "builtin:i3rcStepCloud"), ("flat", flat)):
+        nml = tmp_path / ("%s.nml" % tag)
+        nml.write_text("""&radiativeTransfer
+  solarMu = 1.0, solarAzimuth = 0.0 /
+&monteCarlo
+  numPhotonsPerBatch = %d, numBatches = %d, iseed = 10, nPhaseIntervals = 10001 /
+&algorithms
+  useRayTracing = .true., useRussianRoulette = .true. /
+&output /
+&fileNames
+  physDomainFile = "%s", outputFluxFile = "%s" /
+""" % (ppb, nb, domfile, tmp_path / ("%s_flux.out" % tag)))
+        out = subprocess.check_output([exe, str(nml)], text=True, cwd=str(tmp_path))
+        m = re.search(r"mean flux up/down/absorbed:\s+([\d.]+) \+-\s*([\d.]+)\s+([\d.]+) \+-\s*([\d.]+)\s+([\d.]+) \+-\s*([\d.]+)", out)
+        assert m, out
+        results[tag] = [float(x) for x in m.groups()]
+        rows = [l.split() for l in open(tmp_path / ("%s_flux.out" % tag)) if not l.startswith("!")]
+        assert len(rows) == 32 and len(rows[0]) == 8
+        results[tag + "_cols"] = np.array(rows, float)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=10001, useRayTracing=True, useRussianRoulette=True)
+    photons = M.new_PhotonStream(1.0, 0.0, numberOfPhotons=10 ** 9)
+    integ.resetMoments()
+    integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(10), photons, ppb, nb)
+    st = driver.statistics(driver.unpack_moments(integ.moments(), 32, 1, 32))
+    want = [st["meanFluxUp"], st["meanFluxUp_StdErr"], st["meanFluxDown"], st["meanFluxDown_StdErr"],
+            st["meanFluxAbsorbed"], st["meanFluxAbsorbed_StdErr"]]
+    for tag in ("builtin", "flat"):
+        assert np.allclose(results[tag], want, atol=1.5e-6), (tag, results[tag], want)
+        assert np.allclose(results[tag + "_cols"][:, 2], st["fluxUp"][:, 0], atol=1e-4)
+        assert np.allclose(results[tag + "_cols"][:, 4], st["fluxDown"][:, 0], atol=1e-4)

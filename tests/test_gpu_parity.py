@@ -140,3 +140,77 @@ def test_thermal_emission_matches_oracle(M):
         assert abs(g - r) < 4e-3 * max(abs(r), 0.05), (g, r)
     assert ma < 0  # the layer emits more than it absorbs
     assert np.allclose(res["absorbedProfile"], prof, rtol=0.05, atol=0.02 * np.max(np.abs(prof)))
+
+
+def test_batch_moments_and_split_independence(M):
+    """Moments over several batches equal the oracle's per-batch results folded with the
+    driver's formulas; the same photons traced in one call or split over two calls (what
+    two GPUs would each do) give bitwise identical moment arrays; reruns are bitwise equal."""
+    from mcbrat3d_amd import driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    from oracle import oracle as O
+    ppb, nb = 20000, 4
+    case = cases.step_cloud(ssa=0.99)
+    dom, integ, photons, _ = _setup(M, case)
+
+    integ.resetMoments()
+    rng = new_RandomNumberSequence(SEED)
+    integ.computeRadiativeTransfer(dom, rng, photons, ppb, nb)
+    whole = integ.moments()
+    integ.resetMoments()
+    rng = new_RandomNumberSequence(SEED)
+    integ.computeRadiativeTransfer(dom, rng, photons, ppb, nb)
+    assert np.array_equal(whole, integ.moments())  # fixed-point tallies: run-to-run reproducible
+
+    parts = []
+    for lo in (0, 2):  # "rank 0" takes batches 0-1, "rank 1" batches 2-3
+        integ.resetMoments()
+        rng = new_RandomNumberSequence(SEED, firstPhotonId=lo * ppb)
+        integ.computeRadiativeTransfer(dom, rng, photons, ppb, 2)
+        parts.append(integ.moments())
+    assert np.allclose(parts[0] + parts[1], whole, rtol=1e-14, atol=0)
+
+    P = cases.oracle_problem(case)
+    batches_mean, batches_col = [], []
+    for b in range(nb):
+        r = O.compute_radiative_transfer(P, O.solar_source(1.0, 0.0), O.philox_rng(SEED, b * ppb), ppb)
+        batches_mean.append((ppb, np.array([r["meanFluxUp"], r["meanFluxDown"], r["meanFluxAbsorbed"]], np.float64)))
+        batches_col.append((ppb, r["fluxDown"].astype(np.float64)))
+    mean, err = O.batch_statistics(batches_mean)
+    cmean, cerr = O.batch_statistics(batches_col)
+    st = driver.statistics(driver.unpack_moments(whole, 32, 1, 32))
+    assert st["totalPhotons"] == ppb * nb and st["batches"] == nb
+    got = np.array([st["meanFluxUp"], st["meanFluxDown"], st["meanFluxAbsorbed"]])
+    assert np.all(np.abs(got - mean) < 5.0 / (ppb * nb) + 2e-6)
+    goterr = np.array([st["meanFluxUp_StdErr"], st["meanFluxDown_StdErr"], st["meanFluxAbsorbed_StdErr"]])
+    assert np.allclose(goterr, err, rtol=0.1, atol=2e-4)
+    assert np.max(np.abs(st["fluxDown"][:, 0] - cmean)) < 8.0 * 32 / (ppb * nb)
+
+
+def test_plane_parallel_plumbing(M):
+    """Config 1: 1x1x32 plane-parallel slab, conservative and absorbing, two sun angles: every
+    photon lands in the single column (worst case for tally contention).  With one column the
+    reference's float32 tallies lose precision (1e5 weights of ~0.98 added into a float that has
+    grown past 6.5e4 -- SURVEY.md 8a quirk 6), so the GPU's exact fixed-point sums are compared
+    with the double-precision sum of the oracle's per-photon records; the float32-accumulated
+    oracle result is only required to be within its own rounding error of that."""
+    from oracle import oracle as O
+    n = 100000
+    for ssa, mu0 in ((1.0, 1.0), (0.99, 0.5)):
+        case = cases.plane_parallel(ssa=ssa)
+        dom, integ, photons, rng = _setup(M, case, mu0, 0.0)
+        integ.computeRadiativeTransfer(dom, rng, photons, n)
+        res = integ.reportResults()
+        P = cases.oracle_problem(case)
+        raw = O.compute_rt(P, O.solar_source(mu0, 0.0), O.philox_rng(SEED, 0), n, want_fates=True)
+        f = raw["fates"]
+        up = f["weight"][f["fate"] == 0].astype(np.float64).sum() / n
+        down = f["weight"][f["fate"] == 1].astype(np.float64).sum() / n
+        assert abs(res["meanFluxUp"] - up) < 5.0 / n + 2e-6, (ssa, mu0, res["meanFluxUp"], up)
+        assert abs(res["meanFluxDown"] - down) < 5.0 / n + 2e-6, (ssa, mu0, res["meanFluxDown"], down)
+        assert abs(res["meanFluxAbsorbed"] - (1.0 - up - down)) < 5.0 / n + 2e-6
+        ref = O.normalize(P, n, raw)
+        assert abs(ref["fluxDown"][0] - down) < 5e-4  # the reference's float32 accumulation error
+        if ssa == 1.0:
+            assert res["meanFluxAbsorbed"] == 0.0 and abs(res["meanFluxUp"] + res["meanFluxDown"] - 1.0) < 1e-6
+        integ.finalize()
