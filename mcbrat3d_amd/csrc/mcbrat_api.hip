@@ -58,6 +58,8 @@ struct mcbrat_ctx {
   int blocksPerCU = 0;  // 0: from the occupancy query
   int eventThreshold = 40;
   int maxBatchesInFlight = 0;  // 0: bounded by memory
+  int privMode = 1;            // 1: LDS-private tallies when the slab fits, 0: always global atomics
+  int blockSize = 0;           // 0: chosen by plan_launch
   bool countersOn = false;
   float lastTraceMs = 0.f;
   mcbrat_counters lastCounters{};
@@ -150,32 +152,66 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
 }
 
-size_t lds_bytes(const mcbrat_ctx *c, bool tblLds) {
-  size_t b = sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3);
-  if (tblLds) b += sizeof(float) * (size_t)c->tblTotalFloats;
-  return b;
-}
-constexpr size_t kTableLdsLimit = 48 * 1024;  // above this the tables stay in L2
+constexpr size_t kLdsBudget = 64 * 1024;      // default dynamic-LDS limit per workgroup
+constexpr size_t kTableLdsLimit = 48 * 1024;   // tables above this stay in L2
+constexpr size_t kPrivSlabLimit = 32 * 1024;   // private tally slab above this -> global atomics
 
-template <bool TBL, bool DBG>
-int launch_trace_t(mcbrat_ctx *c, const DevParams &p, size_t lds) {
+struct LaunchPlan {
+  bool tblLds, priv;
+  int block;
+  size_t lds;
+};
+
+LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
+  LaunchPlan L;
+  const size_t edges = sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3);
+  const size_t tbl = sizeof(float) * (size_t)c->tblTotalFloats;
+  const size_t slab = sizeof(long long) * slabStride + 16;
+  L.priv = c->privMode != 0 && slab <= kPrivSlabLimit;
+  L.tblLds = tbl <= kTableLdsLimit && edges + tbl + (L.priv ? slab : 0) <= kLdsBudget;
+  if (L.priv && edges + slab + (L.tblLds ? tbl : 0) > kLdsBudget) L.priv = false;
+  L.lds = edges + (L.priv ? slab : 0) + (L.tblLds ? tbl : 0);
+  L.block = c->blockSize > 0 ? c->blockSize : ((L.tblLds || L.priv) && L.lds > 16 * 1024 ? 512 : 256);
+  return L;
+}
+
+template <int BLOCK, bool TBL, bool PRIV, bool DBG>
+int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   int perCU = c->blocksPerCU;
   if (perCU <= 0) {
-    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<TBL, DBG>, kBlock, lds));
+    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, DBG>, BLOCK, lds));
     perCU = std::max(1, std::min(perCU, 8));
   }
-  unsigned long long needed = (p.total + kBlock - 1) / kBlock;
-  unsigned grid = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)perCU * c->numCUs, needed));
-  hipLaunchKernelGGL((trace_kernel<TBL, DBG>), dim3(grid), dim3(kBlock), lds, c->stream, p);
+  unsigned long long blocks = (unsigned long long)perCU * c->numCUs;
+  if (PRIV) {
+    // every workgroup traces photons of one batch at a time: cut each batch into units so that
+    // there is about one unit per resident workgroup
+    unsigned long long upb = std::max<unsigned long long>(1, blocks / (unsigned long long)nBatches);
+    upb = std::min<unsigned long long>(upb, std::max<unsigned long long>(1, p.ppb / (unsigned long long)(BLOCK * 8)));
+    p.unitsPerBatch = upb;
+    p.nUnits = upb * (unsigned long long)nBatches;
+    blocks = std::min(blocks, p.nUnits);
+  } else {
+    blocks = std::min(blocks, (p.total + BLOCK - 1) / BLOCK);
+  }
+  const unsigned grid = (unsigned)std::max<unsigned long long>(1, blocks);
+  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, DBG>), dim3(grid), dim3(BLOCK), lds, c->stream, p);
   HIP_OK(c, hipGetLastError());
   return 0;
 }
 
-int launch_trace(mcbrat_ctx *c, const DevParams &p, bool debug) {
-  const bool tblLds = sizeof(float) * (size_t)c->tblTotalFloats <= kTableLdsLimit;
-  const size_t lds = lds_bytes(c, tblLds);
-  if (tblLds) return debug ? launch_trace_t<true, true>(c, p, lds) : launch_trace_t<true, false>(c, p, lds);
-  return debug ? launch_trace_t<false, true>(c, p, lds) : launch_trace_t<false, false>(c, p, lds);
+template <int BLOCK, bool DBG>
+int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatches) {
+  if (L.tblLds) return L.priv ? launch_trace_t<BLOCK, true, true, DBG>(c, p, L.lds, nBatches)
+                              : launch_trace_t<BLOCK, true, false, DBG>(c, p, L.lds, nBatches);
+  return L.priv ? launch_trace_t<BLOCK, false, true, DBG>(c, p, L.lds, nBatches)
+                : launch_trace_t<BLOCK, false, false, DBG>(c, p, L.lds, nBatches);
+}
+
+int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
+  const LaunchPlan L = plan_launch(c, (size_t)p.slabStride);
+  if (L.block == 512) return debug ? launch_trace_b<512, true>(c, p, L, nBatches) : launch_trace_b<512, false>(c, p, L, nBatches);
+  return debug ? launch_trace_b<256, true>(c, p, L, nBatches) : launch_trace_b<256, false>(c, p, L, nBatches);
 }
 
 int check_ready(mcbrat_ctx *c) {
@@ -407,11 +443,15 @@ int mcbrat_get_counters(mcbrat_ctx *c, mcbrat_counters *out) {
 }
 float mcbrat_last_trace_ms(const mcbrat_ctx *c) { return c ? c->lastTraceMs : 0.f; }
 
-int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight) {
+int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight,
+                      int32_t privateTallies, int32_t blockSize) {
   if (!c) return 1;
   if (blocksPerCU >= 0) c->blocksPerCU = blocksPerCU;
   if (eventThreshold > 0) c->eventThreshold = eventThreshold;
   if (maxBatchesInFlight >= 0) c->maxBatchesInFlight = maxBatchesInFlight;
+  if (privateTallies >= 0) c->privMode = privateTallies ? 1 : 0;
+  if (blockSize == 0 || blockSize == 256 || blockSize == 512) c->blockSize = blockSize;
+  else if (blockSize > 0) return fail(c, "set_tuning: blockSize must be 0, 256 or 512");
   return 0;
 }
 
@@ -461,14 +501,15 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     HIP_OK(c, hipMemsetAsync(c->dSlabs, 0, sizeof(long long) * slabStride * nb, c->stream));  // zero tallies :248-252
     HIP_OK(c, hipMemsetAsync(c->dCounter, 0, sizeof(unsigned long long), c->stream));
     HIP_OK(c, hipEventRecord(c->ev0, c->stream));
-    if (launch_trace(c, p, c->countersOn)) return 1;
+    if (launch_trace(c, p, c->countersOn, nb)) return 1;
     HIP_OK(c, hipEventRecord(c->ev1, c->stream));
     FinishParams f;
     f.nx = c->nx; f.ny = c->ny; f.nz = c->nz; f.nBatches = nb; f.xyRegular = c->xyRegular;
     f.ppb = p.ppb; f.total = p.total; f.slabStride = slabStride;
     f.slabs = c->dSlabs; f.relArea = c->dRelArea; f.ze = c->dEdges + (c->nx + 1) + (c->ny + 1);
     f.colVals = c->dColVals; f.scalVals = c->dScalVals; f.moments = c->dMoments; f.last = c->dLast;
-    hipLaunchKernelGGL(finish_columns, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, c->stream, f);
+    hipLaunchKernelGGL(finish_columns, dim3((unsigned)((ncol * (size_t)nb + 255) / 256)), dim3(256), 0, c->stream, f);
+    hipLaunchKernelGGL(finish_column_moments, dim3((unsigned)((3 * ncol + 255) / 256)), dim3(256), 0, c->stream, f);
     hipLaunchKernelGGL(finish_volume, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, c->stream, f);
     hipLaunchKernelGGL(finish_reduce, dim3(3 + c->nz, nb), dim3(256), 0, c->stream, f);
     hipLaunchKernelGGL(finish_scalars, dim3((unsigned)((3 + c->nz + 255) / 256)), dim3(256), 0, c->stream, f);
@@ -531,7 +572,7 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
   p.slabs = scratch; p.slabStride = slabStride;
   p.ppb = (unsigned long long)n; p.total = (unsigned long long)n; p.firstPhoton = firstPhotonId;
   p.fates = dF; p.counters = c->dEventCounters;
-  int rc = launch_trace(c, p, true);
+  int rc = launch_trace(c, p, true, 1);
   if (!rc) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(fates, dF, sizeof(mcbrat_fate) * (size_t)n, hipMemcpyDeviceToHost);

@@ -50,6 +50,8 @@ struct DevParams {
   uint32_t seedLo, seedHi;
   long long *slabs;               // per batch: [fluxUp(ncol) | fluxDown(ncol) | volume(nvox)]
   unsigned long long slabStride;  // in elements
+  unsigned long long nUnits;      // PRIV mode: work units (each inside one batch) ...
+  unsigned long long unitsPerBatch;  // ... and how many of them a batch is cut into
   int eventThreshold;             // process events when fewer than this many lanes are walking
   // debug / measurement
   mcbrat_fate *fates;             // non-null: record per-photon fate (index = photon index)

@@ -8,40 +8,42 @@
 // Drivers/monteCarloDriver.f95:1023-1050).
 //
 // Design (MI355X first, not a translation):
-//  * one photon per work-item, persistent 64-wide waves; a wave pulls chunks of photon ids
-//    from one global counter and hands them to its idle lanes with ballot/popcount ranks
-//    (regeneration: a lane whose photon left the domain, was absorbed by the surface or lost
-//    at Russian roulette is refilled, so dead lanes never ride along);
-//  * the loop is flattened: every iteration each walking lane advances exactly one voxel
-//    face; launches / collisions / surface reflections are deferred until enough lanes of
-//    the wave wait for them (eventThreshold), which keeps both halves of the loop dense;
-//  * cell-authoritative voxel walk: per-axis parametric distance to the next face is kept in
-//    registers and only the crossed axis is updated; the position is materialised once per
-//    leg (statistically, not bitwise, identical to the reference's position-stepping walk);
-//  * counter-based Philox4x32-10: key = seed, counter = (event, block, photon id).  Each role
-//    has a fixed slot so that one block per leg serves (tau, component, roulette, angle):
-//       event 0 (launch)   block 0 = [x, y, -, -]                      (solar source)
-//                          block 0 = [select, r1, r2, r3], block 1.. (emission source)
-//       event e >= 1       block 0 = [tau, A, B, C]
-//            collision: component = A, roulette = B, angle = C,
-//                       next_direct round k -> block 1 + k/2, elements 2(k&1), 2(k&1)+1
-//            surface:   mu = sqrt(A) (retry C, then block 1..), phi = 2 pi B
-//    (the oracle's Philox mode uses the same table);
+//  * one photon per work-item in persistent 64-wide waves.  Idle lanes are refilled in place
+//    (regeneration) with ballot/popcount ranks: from a chunk of photon ids the wave took from
+//    one global counter, or -- PRIV mode -- from the workgroup's own range via an LDS counter.
+//  * the loop is split in two dense halves.  A tight walk loop in which every walking lane
+//    crosses exactly one voxel face per iteration, branch-free, runs until fewer than
+//    `eventThreshold` lanes of the wave are still walking; then one event phase serves all
+//    waiting lanes at once (launch, collision, surface reflection, next leg set-up).
+//  * cell-authoritative voxel walk: the distance along the leg to the next x/y/z face is kept
+//    per axis in registers (float), only the crossed axis is updated from the edge table in
+//    LDS; periodic wrap shifts the leg origin; the position (double, as in the reference) is
+//    materialised once per leg.  Statistically, not bitwise, identical to the reference's
+//    position-stepping walk with spacing() snaps.
+//  * counter-based Philox4x32-10: key = seed, counter = (event, block, photon id).  Roles have
+//    fixed slots so that ONE block serves a whole leg in the common case:
+//       event 0 (launch)   block 0 = [x, y, -, -]                        (solar source)
+//                          block 0 = [select, r1, r2, r3], block 1..   (emission source)
+//       event e >= 1       block 0 = [tau, X, Y, Z], block 1 = [component, roulette, -, -]
+//            collision: angle = X, next_direct round 0 = (Y, Z), round k>=1 -> block 2+(k-1)/2
+//            surface:   mu = sqrt(X) (retry Z, then block 2..), phi = 2 pi Y
+//    block 1 is only generated when it is used (nc > 1, or weight < 1/2 with roulette on).
+//    The oracle's Philox mode uses the same table (oracle/mcbrat_oracle.c).
 //  * cell edges and, when they fit, the inverse phase-function tables are staged in LDS by
-//    coalesced loads; extinction / ssa / phase index are float / float / u16 grids in HBM
-//    that stay resident in L2 + Infinity Cache;
-//  * tallies are signed 64-bit fixed point (2^-32) added with global atomics into one slab
-//    per batch: integer sums are order-independent, so results are bitwise reproducible and
-//    independent of the number of GPUs.  fluxAbsorbed is the column sum of the volume tally
-//    (the reference adds the same deposit to both, :766-769).
+//    coalesced loads; extinction / ssa / phase index are float / float / u16 grids in HBM that
+//    stay resident in L1/L2/Infinity Cache.
+//  * tallies are signed 64-bit fixed point (2^-32): integer sums are order independent, so
+//    results are bitwise reproducible and independent of the number of GPUs.  Small domains
+//    (PRIV): each workgroup traces photons of ONE batch and tallies into an LDS slab that is
+//    flushed once with global atomics; large domains: global atomics into the batch's slab.
+//    fluxAbsorbed is the column sum of the volume tally (same deposits, :766-769).
 #include <float.h>
 
 #include "mcbrat_device.h"
 
 namespace mcbrat {
 
-constexpr int kBlock = 256;
-constexpr unsigned long long kChunk = 256;  // photon ids a wave takes per global atomic
+constexpr unsigned kChunk = 256;  // photon ids a wave takes per global atomic (global mode)
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&out)[4]) {
@@ -69,15 +71,14 @@ __device__ __forceinline__ uint32_t pick4(const uint32_t (&r)[4], uint32_t i) {
   return (i & 2u) ? b : a;
 }
 
-__device__ __forceinline__ void tally_add(long long *addr, double v) {
-  atomicAdd(reinterpret_cast<unsigned long long *>(addr),
-            static_cast<unsigned long long>(__double2ll_rn(v * kTallyScale)));
+__device__ __forceinline__ unsigned long long to_fixed(double v) {
+  return (unsigned long long)__double2ll_rn(v * kTallyScale);
 }
 
 // findIndex(value, table) for cell edges: largest i with e[i] <= v, clamped to [0, n-1]
 // (src/numericUtilities.f95:207-260, no first guess).
 __device__ __forceinline__ int find_cell(const double *e, int n, double v) {
-  int lo = 0, hi = n;  // cells lo..hi-1
+  int lo = 0, hi = n;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (v >= e[mid]) lo = mid; else hi = mid;
@@ -97,86 +98,114 @@ __device__ __forceinline__ int find_cdf(const double *t, int n, long long stride
   return hi;
 }
 
-template <bool TBL_LDS, bool DEBUG>
-__global__ void __launch_bounds__(kBlock) trace_kernel(const DevParams p) {
+template <int BLOCK, bool TBL_LDS, bool PRIV, bool DEBUG>
+__global__ void __launch_bounds__(BLOCK) trace_kernel(const DevParams p) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  double *s_xe = reinterpret_cast<double *>(smem_raw);
-  double *s_ye = s_xe + (p.nx + 1);
-  double *s_ze = s_ye + (p.ny + 1);
-  float *s_tbl = reinterpret_cast<float *>(s_ze + (p.nz + 1));
-  {
-    const int nEdges = p.nx + p.ny + p.nz + 3;
-    for (int i = threadIdx.x; i < nEdges; i += kBlock) s_xe[i] = p.edges[i];
-    if (TBL_LDS)
-      for (int i = threadIdx.x; i < p.tblTotalFloats; i += kBlock) s_tbl[i] = p.tables[i];
-    __syncthreads();
+  // LDS map: [edges x|y|z (double)] [private tally slab (i64), PRIV] [unit cursor, PRIV] [tables (float), TBL_LDS]
+  double *s_edge = reinterpret_cast<double *>(smem_raw);
+  const int nEdges = p.nx + p.ny + p.nz + 3;
+  const int ncol = p.nx * p.ny;
+  const int slabLen = PRIV ? (int)p.slabStride : 0;
+  long long *s_slab = reinterpret_cast<long long *>(s_edge + nEdges);
+  unsigned *s_cursor = reinterpret_cast<unsigned *>(s_slab + slabLen);
+  float *s_tbl = reinterpret_cast<float *>(s_cursor + (PRIV ? 4 : 0));
+  for (int i = threadIdx.x; i < nEdges; i += BLOCK) s_edge[i] = p.edges[i];
+  if (TBL_LDS)
+    for (int i = threadIdx.x; i < p.tblTotalFloats; i += BLOCK) s_tbl[i] = p.tables[i];
+  if (PRIV) {
+    for (int i = threadIdx.x; i < slabLen; i += BLOCK) s_slab[i] = 0;
+    if (threadIdx.x == 0) s_cursor[0] = 0;
   }
+  __syncthreads();
   const float *__restrict__ tbl = TBL_LDS ? s_tbl : p.tables;
+  const int offY = p.nx + 1, offZ = p.nx + p.ny + 2;  // edge table offsets
 
   const int lane = threadIdx.x & (kWave - 1);
   const unsigned long long laneBelow = (1ull << lane) - 1ull;
-  const int ncol = p.nx * p.ny;
-  const double zSurf = p.zSurf;
 
-  // lane state ------------------------------------------------------------------
+  // PRIV: this workgroup's unit = photons [unitFirst, unitFirst + unitCount) of ONE batch
+  unsigned long long unitFirst = 0;
+  unsigned unitCount = 0;
+  long long *unitSlab = nullptr;
+
+  // lane state --------------------------------------------------------------------------
   int state = ST_DEAD;
   bool more = true;
-  unsigned long long g = 0;  // photon index inside this launch
-  uint32_t idLo = 0, idHi = 0, event = 0;
-  double px = 0, py = 0, pz = 0;          // leg origin
-  float dx = 0, dy = 0, dz = 1;           // direction cosines
-  double ivx = 0, ivy = 0, ivz = 0;       // 1/direction
-  double tnx = 0, tny = 0, tnz = 0, tcur = 0;  // distance along the leg to the next x/y/z face
-  float acc = 0, tau = 0, w = 0, extCur = 0, uA = 0, uB = 0, uC = 0;
-  int ix = 0, iy = 0, iz = 0, wx = 0, wy = 0;
+  uint32_t idLo = 0, idHi = 0, event = 0, batch = 0;
+  double px = 0, py = 0, pz = 0;      // leg origin (in the periodic image the walk is currently in)
+  float dx = 0, dy = 0, dz = 1;       // direction cosines
+  float ivx = 0, ivy = 0, ivz = 0;    // 1/direction
+  float tnx = 0, tny = 0, tnz = 0, tcur = 0;  // distance along the leg to the next x/y/z face
+  float acc = 0, tau = 0, w = 0, extCur = 0, uX = 0, uY = 0, uZ = 0;
+  int ix = 0, iy = 0, iz = 0;
   int nScat = 0, nLegs = 0;
-  unsigned long long chunkNext = 0, chunkEnd = 0;  // wave-uniform
-  // DEBUG counters (per lane, flushed at the end)
+  unsigned long long chunkNext = 0, chunkEnd = 0;  // global mode, wave-uniform
   unsigned int cLegs = 0, cCross = 0, cColl = 0, cAbs = 0, cTop = 0, cSurf = 0, cKill = 0, cSurv = 0;
 
-  for (;;) {
-    const int nWalk = __popcll(__ballot(state == ST_WALK));
-    if (nWalk < p.eventThreshold) {  // wave-uniform
+  for (unsigned long long unit = blockIdx.x;; unit += gridDim.x) {
+    if (PRIV) {  // workgroup-uniform
+      if (unit >= p.nUnits) break;
+      const unsigned long long b = unit / p.unitsPerBatch, s = unit % p.unitsPerBatch;
+      const unsigned long long bp = (p.total - b * p.ppb) < p.ppb ? (p.total - b * p.ppb) : p.ppb;
+      const unsigned long long lo = (bp * s) / p.unitsPerBatch, hi = (bp * (s + 1)) / p.unitsPerBatch;
+      unitFirst = b * p.ppb + lo;
+      unitCount = (unsigned)(hi - lo);
+      unitSlab = p.slabs + b * p.slabStride;
+      batch = (uint32_t)b;
+      more = true;
+    }
+
+    for (;;) {
+      // ================= event phase: every lane that is not walking =====================
       bool needLeg = false;
-      // ---- regeneration: hand photon ids to idle lanes --------------------------
       const unsigned long long want = __ballot(state == ST_DEAD && more);
       if (want != 0ull) {  // wave-uniform
         const int nWant = __popcll(want);
         const int rank = __popcll(want & laneBelow);
-        unsigned long long myId = chunkNext + (unsigned long long)rank;
-        const unsigned long long avail = chunkEnd - chunkNext;
-        if (avail < (unsigned long long)nWant) {  // wave-uniform: take a new chunk
-          unsigned long long base = 0;
-          if (lane == 0) base = atomicAdd(p.counter, kChunk);
-          const uint32_t bl = __shfl((int)(uint32_t)base, 0), bh = __shfl((int)(uint32_t)(base >> 32), 0);
-          base = ((unsigned long long)bh << 32) | bl;
-          if ((unsigned long long)rank >= avail) myId = base + ((unsigned long long)rank - avail);
-          chunkNext = base + ((unsigned long long)nWant - avail);
-          chunkEnd = base + kChunk;
+        unsigned long long myIdx;  // photon index inside this launch
+        bool valid;
+        if (PRIV) {
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(&s_cursor[0], (unsigned)nWant);
+          base = (unsigned)__shfl((int)base, 0);
+          const unsigned k = base + (unsigned)rank;
+          valid = k < unitCount;
+          myIdx = unitFirst + k;
         } else {
-          chunkNext += (unsigned long long)nWant;
+          myIdx = chunkNext + (unsigned long long)rank;
+          const unsigned long long avail = chunkEnd - chunkNext;
+          if (avail < (unsigned long long)nWant) {  // wave-uniform: take a new chunk
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(p.counter, (unsigned long long)kChunk);
+            const uint32_t bl = __shfl((int)(uint32_t)base, 0), bh = __shfl((int)(uint32_t)(base >> 32), 0);
+            base = ((unsigned long long)bh << 32) | bl;
+            if ((unsigned long long)rank >= avail) myIdx = base + ((unsigned long long)rank - avail);
+            chunkNext = base + ((unsigned long long)nWant - avail);
+            chunkEnd = base + kChunk;
+          } else {
+            chunkNext += (unsigned long long)nWant;
+          }
+          valid = myIdx < p.total;
         }
         if (state == ST_DEAD && more) {
-          if (myId < p.total) {
-            // ---- launch: getNextPhoton + computeRT :466-508 ------------------------
-            g = myId;
-            const unsigned long long id = p.firstPhoton + g;
+          if (valid) {
+            // ---- launch: getNextPhoton + computeRT :466-508 --------------------------------
+            if (!PRIV) batch = (uint32_t)(myIdx / p.ppb);
+            const unsigned long long id = p.firstPhoton + myIdx;
             idLo = (uint32_t)id; idHi = (uint32_t)(id >> 32);
             event = 0; nScat = 0; nLegs = 0;
             uint32_t r[4];
             philox4x32_10(0u, 0u, idLo, idHi, p.seedLo, p.seedHi, r);
             double fx, fy, fz;  // fractional launch position in [0,1]
-            float mu = 0.f, phi = 0.f;
-            bool fromSurface = false;
             if (p.srcKind == 0) {  // newPhotonStream_Directional, monteCarloIllumination.f95:88-96
               fx = (double)u01(r[0]);
               fy = (double)u01(r[1]);
               fz = 0.0;
               dx = p.dir0[0]; dy = p.dir0[1]; dz = p.dir0[2];
             } else {  // newPhotonStream_BBEmission :481-516
+              float mu = 0.f, phi = 0.f;
               const float sel = u01(r[0]);
               if ((double)sel > p.fracAtms) {  // surface emission :484-493
-                fromSurface = true;
                 fx = (double)u01(r[1]);
                 fy = (double)u01(r[2]);
                 fz = 0.0;
@@ -223,8 +252,8 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const DevParams p) {
               ix = min((int)((px - p.x0) * p.invDX), p.nx - 1);
               iy = min((int)((py - p.y0) * p.invDY), p.ny - 1);
             } else {
-              ix = find_cell(s_xe, p.nx, px);
-              iy = find_cell(s_ye, p.ny, py);
+              ix = find_cell(s_edge, p.nx, px);
+              iy = find_cell(s_edge + offY, p.ny, py);
             }
             if (p.srcKind == 0) {
               pz = p.zLaunch; iz = p.izLaunch;
@@ -235,66 +264,79 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const DevParams p) {
               const double t = (fz - p.z0) * (double)p.nz;
               const double fl = floor(t);
               iz = min((int)fl, p.nz - 1);
-              pz = s_ze[iz] + (t - fl) * (s_ze[iz + 1] - s_ze[iz]);
+              pz = s_edge[offZ + iz] + (t - fl) * (s_edge[offZ + iz + 1] - s_edge[offZ + iz]);
             }
+            extCur = p.ext[ix + p.nx * (iy + p.ny * iz)];
             if (p.lwFlag && pz > 0.0) {  // :504-508 emission counts as negative absorption
-              long long *slab = p.slabs + (g / p.ppb) * p.slabStride;
-              tally_add(slab + 2 * ncol + (ix + p.nx * (iy + p.ny * iz)), -1.0);
+              const int cell = ix + p.nx * (iy + p.ny * iz);
+              if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + cell), to_fixed(-1.0));
+              else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + 2 * ncol + cell), to_fixed(-1.0));
             }
-            (void)fromSurface;
             needLeg = true;
           } else {
             more = false;
           }
         }
       }
-      // ---- deferred events ------------------------------------------------------
+      // ---- deferred events -------------------------------------------------------------
       if (state == ST_COLLIDE) {
-        // scattering event, computeRT :703-821 (zero-extinction back-step :728-754 cannot
+        // scattering event, computeRT :703-821 (the zero-extinction back-step :728-754 cannot
         // arise: a collision is only declared inside a cell with extinction > 0)
         nScat++;
         if (DEBUG) cColl++;
         const int cell = ix + p.nx * (iy + p.ny * iz);
         const long long nvox = (long long)ncol * p.nz;
+        uint32_t r1[4] = {0u, 0u, 0u, 0u};
+        bool haveR1 = false;
         int c = 0;  // component pick :759-760 (findIndex over [0, cumExt(:)])
-        for (int k = 0; k < p.nc - 1; k++)
-          if (uA >= p.cum[(long long)k * nvox + cell]) c = k + 1;
+        if (p.nc > 1) {
+          philox4x32_10(event, 1u, idLo, idHi, p.seedLo, p.seedHi, r1);
+          haveR1 = true;
+          const float uA = u01(r1[0]);
+          for (int k = 0; k < p.nc - 1; k++)
+            if (uA >= p.cum[(long long)k * nvox + cell]) c = k + 1;
+        }
         const float ssa = p.ssa[(long long)c * nvox + cell];
         if (ssa < 1.0f) {  // absorption :765-771
-          long long *slab = p.slabs + (g / p.ppb) * p.slabStride;
-          tally_add(slab + 2 * ncol + cell, (double)w * (1.0 - (double)ssa));
+          const unsigned long long dep = to_fixed((double)w * (1.0 - (double)ssa));
+          if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + cell), dep);
+          else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + 2 * ncol + cell), dep);
           w = w * ssa;
           if (DEBUG) cAbs++;
         }
         if (p.useRR && w < 0.5f) {  // Russian roulette :805-811, RussianRouletteW = 1
-          if (uB >= w) { w = 0.0f; if (DEBUG) cKill++; }
+          if (!haveR1) philox4x32_10(event, 1u, idLo, idHi, p.seedLo, p.seedHi, r1);
+          if (u01(r1[1]) >= w) { w = 0.0f; if (DEBUG) cKill++; }
           else { w = 1.0f; if (DEBUG) cSurv++; }
         }
         if (w <= FLT_MIN) {  // :812
-          if (DEBUG && p.fates) p.fates[g] = mcbrat_fate{2, ix + 1, iy + 1, iz + 1, nScat, nLegs, 0.0f};
+          if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{2, ix + 1, iy + 1, iz + 1, nScat, nLegs, 0.0f};
           state = ST_DEAD;
         } else {
           // computeScatteringAngle :1594-1621 (table point count N, floor-type lookup as written)
           const int pf = p.pfi[(long long)c * nvox + cell];
           const int n = p.tblNSteps[c];
           const float *t = tbl + p.tblOffset[c] + (long long)pf * n;
-          const int ai = (int)(uC * (float)n) + 1;
+          const int ai = (int)(uX * (float)n) + 1;
           float ang;
           if (ai < n) {
-            const float left = uC - (float)(ai - 1) / (float)n;
+            const float left = uX - (float)(ai - 1) / (float)n;
             ang = (1.0f - left) * t[ai - 1] + left * t[ai];
           } else {
             ang = t[n - 1];
           }
           const float cs = cosf(ang);
           // next_direct :1921-1948
-          float AX = 0.f, AY = 0.f, D = 2.0f;
-          uint32_t r[4];
-          for (uint32_t k = 0; D > 1.0f; k++) {
-            if ((k & 1u) == 0) philox4x32_10(event, 1u + (k >> 1), idLo, idHi, p.seedLo, p.seedHi, r);
-            AX = 1.0f - 2.0f * u01((k & 1u) ? r[2] : r[0]);
-            AY = 1.0f - 2.0f * u01((k & 1u) ? r[3] : r[1]);
-            D = AX * AX + AY * AY;
+          float AX = 1.0f - 2.0f * uY, AY = 1.0f - 2.0f * uZ;
+          float D = AX * AX + AY * AY;
+          if (D > 1.0f) {
+            uint32_t r[4];
+            for (uint32_t k = 0; D > 1.0f; k++) {
+              if ((k & 1u) == 0) philox4x32_10(event, 2u + (k >> 1), idLo, idHi, p.seedLo, p.seedHi, r);
+              AX = 1.0f - 2.0f * u01((k & 1u) ? r[2] : r[0]);
+              AY = 1.0f - 2.0f * u01((k & 1u) ? r[3] : r[1]);
+              D = AX * AX + AY * AY;
+            }
           }
           float B = sqrtf((1.0f - cs * cs) / D);
           AX = AX * B;
@@ -307,25 +349,26 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const DevParams p) {
           needLeg = true;
         }
       } else if (state == ST_SURFACE) {
-        // surface, computeRT :619-676 (Lambertian)
-        long long *slab = p.slabs + (g / p.ppb) * p.slabStride;
-        tally_add(slab + ncol + (ix + p.nx * iy), (double)w);  // fluxDown gets the incident weight :634
+        // surface, computeRT :619-676 (Lambertian); fluxDown gets the incident weight :634
+        const unsigned long long dep = to_fixed((double)w);
+        if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + ncol + (ix + p.nx * iy)), dep);
+        else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + ncol + (ix + p.nx * iy)), dep);
         nScat++;
         if (DEBUG) cSurf++;
-        float mu = sqrtf(uA);
+        float mu = sqrtf(uX);
         if (!(fabsf(mu) > 2.0f * FLT_MIN)) {
-          mu = sqrtf(uC);
+          mu = sqrtf(uZ);
           uint32_t r[4];
           for (uint32_t j = 0; !(fabsf(mu) > 2.0f * FLT_MIN); j++) {
-            if ((j & 3u) == 0) philox4x32_10(event, 1u + (j >> 2), idLo, idHi, p.seedLo, p.seedHi, r);
+            if ((j & 3u) == 0) philox4x32_10(event, 2u + (j >> 2), idLo, idHi, p.seedLo, p.seedHi, r);
             mu = sqrtf(u01(pick4(r, j & 3u)));
           }
         }
-        const float phi = (2.0f * 3.14159274f) * uB;
+        const float phi = (2.0f * 3.14159274f) * uY;
         const float wIn = w;
         w = (float)((double)w * (double)p.albedo);  // :673
         if (w <= FLT_MIN) {
-          if (DEBUG && p.fates) p.fates[g] = mcbrat_fate{1, ix + 1, iy + 1, 1, nScat, nLegs, wIn};
+          if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{1, ix + 1, iy + 1, 1, nScat, nLegs, wIn};
           state = ST_DEAD;
         } else {
           const float sinTheta = sqrtf(1.0f - mu * mu);
@@ -333,76 +376,102 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const DevParams p) {
           needLeg = true;
         }
       }
-      // ---- start the next leg: tau and the per-axis face distances -------------------
+      // ---- start the next leg: tau and the per-axis face distances -------------------------
       if (needLeg) {
         event++;
         nLegs++;
         if (DEBUG) cLegs++;
         uint32_t r[4];
         philox4x32_10(event, 0u, idLo, idHi, p.seedLo, p.seedHi, r);
-        const float u = u01(r[0]);
-        tau = -logf(fmaxf(FLT_MIN, u));  // :554
-        uA = u01(r[1]); uB = u01(r[2]); uC = u01(r[3]);
-        acc = 0.0f; tcur = 0.0; wx = 0; wy = 0;
-        // opticalProperties.f95:1690-1712: side 1 where direction >= 0
-        if (fabsf(dx) >= 2.0f * FLT_MIN) { ivx = 1.0 / (double)dx; tnx = (s_xe[ix + (dx >= 0.0f ? 1 : 0)] - px) * ivx; }
-        else { ivx = 0.0; tnx = DBL_MAX; }
-        if (fabsf(dy) >= 2.0f * FLT_MIN) { ivy = 1.0 / (double)dy; tny = (s_ye[iy + (dy >= 0.0f ? 1 : 0)] - py) * ivy; }
-        else { ivy = 0.0; tny = DBL_MAX; }
-        if (fabsf(dz) >= 2.0f * FLT_MIN) { ivz = 1.0 / (double)dz; tnz = (s_ze[iz + (dz >= 0.0f ? 1 : 0)] - pz) * ivz; }
-        else { ivz = 0.0; tnz = DBL_MAX; }
-        extCur = p.ext[ix + p.nx * (iy + p.ny * iz)];
+        tau = -logf(fmaxf(FLT_MIN, u01(r[0])));  // :554
+        uX = u01(r[1]); uY = u01(r[2]); uZ = u01(r[3]);
+        acc = 0.0f; tcur = 0.0f;
+        // opticalProperties.f95:1690-1712: side 1 where direction >= 0; huge step for a zero cosine
+        if (fabsf(dx) >= 2.0f * FLT_MIN) { ivx = 1.0f / dx; tnx = (float)(s_edge[ix + (dx >= 0.0f ? 1 : 0)] - px) * ivx; }
+        else { ivx = 0.0f; tnx = FLT_MAX; }
+        if (fabsf(dy) >= 2.0f * FLT_MIN) { ivy = 1.0f / dy; tny = (float)(s_edge[offY + iy + (dy >= 0.0f ? 1 : 0)] - py) * ivy; }
+        else { ivy = 0.0f; tny = FLT_MAX; }
+        if (fabsf(dz) >= 2.0f * FLT_MIN) { ivz = 1.0f / dz; tnz = (float)(s_edge[offZ + iz + (dz >= 0.0f ? 1 : 0)] - pz) * ivz; }
+        else { ivz = 0.0f; tnz = FLT_MAX; }
         state = ST_WALK;
       }
-      if (__ballot(state != ST_DEAD) == 0ull) break;  // wave-uniform: nothing alive, nothing left
-    }
+      if (__ballot(state != ST_DEAD) == 0ull) break;  // wave-uniform: nothing alive, nothing left in this unit
 
-    // ---- one face per iteration: accumulateExtinctionAlongPath :1697-1814 --------------
-    if (state == ST_WALK) {
-      double tmin = tnx;
-      int ax = 0;
-      if (tny < tmin) { tmin = tny; ax = 1; }
-      if (tnz < tmin) { tmin = tnz; ax = 2; }
-      const double dtau = (tmin - tcur) * (double)extCur;
-      if ((double)acc + dtau > (double)tau) {
-        // :1729-1738 stop inside this cell
-        const double s = tcur + (double)(tau - acc) / (double)extCur;
-        px = px + s * (double)dx - (double)wx * p.Lx;
-        py = py + s * (double)dy - (double)wy * p.Ly;
-        pz = pz + s * (double)dz;
-        state = ST_COLLIDE;
-      } else {
-        acc = (float)((double)acc + dtau);  // :1743
-        tcur = tmin;
-        if (DEBUG) cCross++;
-        if (ax == 0) {
-          if (dx >= 0.0f) { if (++ix == p.nx) { ix = 0; wx++; } }
-          else { if (--ix < 0) { ix = p.nx - 1; wx--; } }  // periodic :1782-1788
-          tnx = (s_xe[ix + (dx >= 0.0f ? 1 : 0)] + (double)wx * p.Lx - px) * ivx;
-        } else if (ax == 1) {
-          if (dy >= 0.0f) { if (++iy == p.ny) { iy = 0; wy++; } }
-          else { if (--iy < 0) { iy = p.ny - 1; wy--; } }
-          tny = (s_ye[iy + (dy >= 0.0f ? 1 : 0)] + (double)wy * p.Ly - py) * ivy;
-        } else {
-          iz += (dz >= 0.0f) ? 1 : -1;
-          if (iz >= p.nz) {  // out the top :1801-1804, computeRT :573-617
-            long long *slab = p.slabs + (g / p.ppb) * p.slabStride;
-            tally_add(slab + (ix + p.nx * iy), (double)w);
-            if (DEBUG) { cTop++; if (p.fates) p.fates[g] = mcbrat_fate{0, ix + 1, iy + 1, p.nz + 1, nScat, nLegs, w}; }
-            state = ST_DEAD;
-          } else if (iz < 0) {  // hit the bottom :1809-1812, computeRT :619-633
-            px = px + tmin * (double)dx - (double)wx * p.Lx;
-            py = py + tmin * (double)dy - (double)wy * p.Ly;
-            pz = zSurf;
-            iz = 0;
-            state = ST_SURFACE;
+      // ================= walk phase: one voxel face per iteration, branch-free ================
+      // accumulateExtinctionAlongPath :1697-1814
+      int nWalk;
+      do {
+        if (state == ST_WALK) {
+          float tmin = tnx;
+          int ax = 0;
+          if (tny < tmin) { tmin = tny; ax = 1; }
+          if (tnz < tmin) { tmin = tnz; ax = 2; }
+          const float accNew = acc + (tmin - tcur) * extCur;  // :1743
+          if (accNew > tau) {
+            // :1729-1738 stop inside this cell
+            const double s = (double)(tcur + (tau - acc) / extCur);
+            px = px + s * (double)dx;
+            py = py + s * (double)dy;
+            pz = pz + s * (double)dz;
+            state = ST_COLLIDE;
           } else {
-            tnz = (s_ze[iz + (dz >= 0.0f ? 1 : 0)] - pz) * ivz;
+            acc = accNew;
+            tcur = tmin;
+            if (DEBUG) cCross++;
+            const float dAx = ax == 0 ? dx : (ax == 1 ? dy : dz);
+            const int fwd = dAx >= 0.0f ? 1 : 0;
+            int iAx = (ax == 0 ? ix : (ax == 1 ? iy : iz)) + (fwd ? 1 : -1);
+            const int nAx = ax == 0 ? p.nx : (ax == 1 ? p.ny : p.nz);
+            if (ax == 2 && (iAx >= nAx || iAx < 0)) {
+              if (iAx >= nAx) {  // out the top :1801-1804, computeRT :573-617
+                const unsigned long long dep = to_fixed((double)w);
+                if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + (ix + p.nx * iy)), dep);
+                else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + (ix + p.nx * iy)), dep);
+                if (DEBUG) {
+                  cTop++;
+                  if (p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{0, ix + 1, iy + 1, p.nz + 1, nScat, nLegs, w};
+                }
+                state = ST_DEAD;
+              } else {  // hit the bottom :1809-1812, computeRT :619-633
+                px = px + (double)tmin * (double)dx;
+                py = py + (double)tmin * (double)dy;
+                pz = p.zSurf;
+                iz = 0;
+                state = ST_SURFACE;
+              }
+            } else {
+              if (iAx >= nAx) {  // periodic x / y :1782-1796: continue in the next image of the domain
+                iAx = 0;
+                if (ax == 0) px -= p.Lx; else py -= p.Ly;
+              } else if (iAx < 0) {
+                iAx = nAx - 1;
+                if (ax == 0) px += p.Lx; else py += p.Ly;
+              }
+              const double edge = s_edge[(ax == 0 ? 0 : (ax == 1 ? offY : offZ)) + iAx + fwd];
+              const double origin = ax == 0 ? px : (ax == 1 ? py : pz);
+              const float tNew = (float)(edge - origin) * (ax == 0 ? ivx : (ax == 1 ? ivy : ivz));
+              tnx = ax == 0 ? tNew : tnx; tny = ax == 1 ? tNew : tny; tnz = ax == 2 ? tNew : tnz;
+              ix = ax == 0 ? iAx : ix; iy = ax == 1 ? iAx : iy; iz = ax == 2 ? iAx : iz;
+              extCur = p.ext[ix + p.nx * (iy + p.ny * iz)];
+            }
           }
         }
-        if (state == ST_WALK) extCur = p.ext[ix + p.nx * (iy + p.ny * iz)];
+        nWalk = __popcll(__ballot(state == ST_WALK));
+      } while (nWalk >= p.eventThreshold);
+    }
+
+    if (!PRIV) break;
+    // PRIV: flush this unit's private tallies into the batch slab, once
+    __syncthreads();
+    for (int i = threadIdx.x; i < slabLen; i += BLOCK) {
+      const long long v = s_slab[i];
+      if (v != 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(unitSlab + i), (unsigned long long)v);
+        s_slab[i] = 0;
       }
     }
+    if (threadIdx.x == 0) s_cursor[0] = 0;
+    __syncthreads();
   }
 
   if (DEBUG && p.counters) {
@@ -444,34 +513,41 @@ __device__ __forceinline__ unsigned long long batch_photons(const FinishParams &
   return (f.total - start) < f.ppb ? (f.total - start) : f.ppb;
 }
 
+// one thread per (batch, column): normalised column fluxes of every batch (:348-350)
 __global__ void finish_columns(const FinishParams f) {
   const int ncol = f.nx * f.ny;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)ncol * f.nBatches) return;
+  const int col = (int)(i % ncol), b = (int)(i / ncol);
+  const unsigned long long n = batch_photons(f, b);
+  const float nppc = photons_per_column(f, col, n);
+  const long long *slab = f.slabs + (unsigned long long)b * f.slabStride;
+  long long rawAbs = 0;
+  for (int k = 0; k < f.nz; k++) rawAbs += slab[2 * ncol + col + (long long)ncol * k];
+  const long long raw[3] = {slab[col], slab[ncol + col], rawAbs};
+  for (int q = 0; q < 3; q++)
+    f.colVals[((long long)b * 3 + q) * ncol + col] = (float)((double)raw[q] * kTallyInv) / nppc;
+}
+
+// one thread per column flux element: fold batches in order into S1/S2
+__global__ void finish_column_moments(const FinishParams f) {
+  const int ncol = f.nx * f.ny;
   const long long M = 3 + 3LL * ncol + f.nz + (long long)ncol * f.nz;
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= ncol) return;
-  double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
-  float lastv[3] = {0, 0, 0};
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * ncol) return;
+  const int q = i / ncol, col = i % ncol;
+  double s1 = 0, s2 = 0;
+  float lastv = 0;
   for (int b = 0; b < f.nBatches; b++) {
-    const unsigned long long n = batch_photons(f, b);
-    const float nppc = photons_per_column(f, col, n);
-    const long long *slab = f.slabs + (unsigned long long)b * f.slabStride;
-    long long rawAbs = 0;
-    for (int k = 0; k < f.nz; k++) rawAbs += slab[2 * ncol + col + (long long)ncol * k];
-    const long long raw[3] = {slab[col], slab[ncol + col], rawAbs};
-    for (int q = 0; q < 3; q++) {
-      const float v = (float)((double)raw[q] * kTallyInv) / nppc;  // :348-350
-      f.colVals[((long long)b * 3 + q) * ncol + col] = v;
-      s1[q] += (double)v * (double)(long long)n;
-      s2[q] += (double)(long long)n * ((double)v * (double)v);
-      lastv[q] = v;
-    }
+    const double n = (double)(long long)batch_photons(f, b);
+    const float v = f.colVals[((long long)b * 3 + q) * ncol + col];
+    s1 += (double)v * n;
+    s2 += n * ((double)v * (double)v);
+    lastv = v;
   }
-  double *S1 = f.moments + 8, *S2 = f.moments + 8 + M;
-  for (int q = 0; q < 3; q++) {
-    S1[3 + (long long)q * ncol + col] += s1[q];
-    S2[3 + (long long)q * ncol + col] += s2[q];
-    f.last[3 + (long long)q * ncol + col] = lastv[q];
-  }
+  f.moments[8 + 3 + i] += s1;
+  f.moments[8 + M + 3 + i] += s2;
+  f.last[3 + i] = lastv;
 }
 
 __global__ void finish_volume(const FinishParams f) {

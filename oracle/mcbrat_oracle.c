@@ -627,9 +627,10 @@ static float compute_scattering_angle(float u, const float *tbl, int n) { /* :15
 
 static void next_direct(orc_rng *R, float scatteringCosine, float S[3]) { /* :1921-1948 */
   float D = 2.0f, AX = 0.f, AY = 0.f, B;
-  for (uint32_t k = 0; D > 1.0f; k++) { /* Philox slots: round k = block 1+k/2, elems 2(k&1), 2(k&1)+1 */
-    AX = 1.0f - 2.0f * draw(R, 1 + (k >> 1), 2 * (k & 1));
-    AY = 1.0f - 2.0f * draw(R, 1 + (k >> 1), 2 * (k & 1) + 1);
+  for (uint32_t k = 0; D > 1.0f; k++) { /* Philox slots: round 0 = block 0 elems 2,3; round k>=1 = block 2+(k-1)/2 */
+    const uint32_t blk = k == 0 ? 0u : 2u + ((k - 1) >> 1), el = k == 0 ? 2u : 2u * ((k - 1) & 1u);
+    AX = 1.0f - 2.0f * draw(R, blk, el);
+    AY = 1.0f - 2.0f * draw(R, blk, el + 1);
     D = AX * AX + AY * AY;
   }
   B = sqrtf((1.0f - scatteringCosine * scatteringCosine) / D);
@@ -741,7 +742,7 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
     int fate = -1;
     float fateWeight = 0.0f;
     for (;;) { /* scatteringLoop :548 */
-      if (R->mode == 1) philox_next_event(R); /* event e: block 0 = [tau, A, B, C] */
+      if (R->mode == 1) philox_next_event(R); /* event e: block 0 = [tau, X, Y, Z], block 1 = [component, roulette, -, -] */
       float u = draw(R, 0, 0);
       float tauToTravel = -logf(u > FLT_MIN ? u : FLT_MIN); /* :554 */
       cnt.legs++;
@@ -765,8 +766,8 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
         fluxDown[c2] = fluxDown[c2] + photonWeight;
         cnt.surfaceHits++;
         scatteringOrder++;
-        for (uint32_t j = 0;; j++) { /* Philox slots: mu attempt 0 = A, 1 = C, then block 1.. ; phi = B */
-          mu = sqrtf(j == 0 ? draw(R, 0, 1) : j == 1 ? draw(R, 0, 3) : draw(R, 1 + (j - 2) / 4, (j - 2) % 4));
+        for (uint32_t j = 0;; j++) { /* Philox slots: mu attempt 0 = X, 1 = Z, then block 2.. ; phi = Y */
+          mu = sqrtf(j == 0 ? draw(R, 0, 1) : j == 1 ? draw(R, 0, 3) : draw(R, 2 + (j - 2) / 4, (j - 2) % 4));
           if (fabsf(mu) > 2.0f * FLT_MIN) break;
         }
         phi = (2.0f * Pi) * draw(R, 0, 2);
@@ -806,7 +807,7 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
         double tbl[ORC_MAX_COMPONENTS + 1];
         tbl[0] = 0.0;
         for (int c = 1; c <= nc; c++) tbl[c] = P->cumExt[IDX4(P, xIndex, yIndex, zIndex, c)];
-        int component = orc_find_index_mixed(draw(R, 0, 1), tbl, nc + 1, 0); /* slot A */ /* :759-760 */
+        int component = orc_find_index_mixed(draw(R, 1, 0), tbl, nc + 1, 0); /* block 1 elem 0 */ /* :759-760 */
         if (component < 1) component = 1;
         if (component > nc) component = nc;
         float ssa = (float)P->ssa[IDX4(P, xIndex, yIndex, zIndex, component)]; /* :764 */
@@ -819,14 +820,14 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
           cnt.absorbEvents++;
         }
         if (P->useRussianRoulette && photonWeight < RussianRouletteW / 2.0f) { /* :805-811 */
-          if (draw(R, 0, 2) >= photonWeight / RussianRouletteW) /* slot B */ { photonWeight = 0.0f; cnt.rouletteKills++; }
+          if (draw(R, 1, 1) >= photonWeight / RussianRouletteW) /* block 1 elem 1 */ { photonWeight = 0.0f; cnt.rouletteKills++; }
           else { photonWeight = RussianRouletteW; cnt.rouletteSurvivals++; }
         }
         if (photonWeight <= FLT_MIN) { fate = 2; break; } /* :812 */
         int pfi = P->pfIndex[IDX4(P, xIndex, yIndex, zIndex, component)]; /* :816 */
         int ns = P->invNSteps[component - 1];
         const float *tblf = P->invTables + P->invOffset[component - 1] + (size_t)(pfi - 1) * ns;
-        float scatteringAngle = compute_scattering_angle(draw(R, 0, 3), tblf, ns); /* slot C */
+        float scatteringAngle = compute_scattering_angle(draw(R, 0, 1), tblf, ns); /* slot X */
         next_direct(R, cosf(scatteringAngle), dir); /* :819 */
       }
     }
