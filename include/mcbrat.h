@@ -124,9 +124,10 @@ int mcbrat_get_counters(mcbrat_ctx *ctx, mcbrat_counters *out);
 float mcbrat_last_trace_ms(const mcbrat_ctx *ctx);
 /* Tuning knobs (negative = leave unchanged): workgroups per CU (0 = occupancy query), number of
  * walking lanes below which a wave serves its waiting lanes, batches in flight per launch
- * (0 = memory bound), LDS-private tallies on/off, workgroup size (0 = automatic, 256, 512). */
+ * (0 = memory bound), LDS-private tallies on/off, workgroup size (0 = automatic, 256, 512), and how
+ * many idle / surface lanes queue up before launches / surface reflections are served. */
 int mcbrat_set_tuning(mcbrat_ctx *ctx, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight,
-                      int32_t privateTallies, int32_t blockSize);
+                      int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold);
 
 /* Parity/debug: trace n photons (ids firstPhotonId..) and record what became
  * of each one.  Tallies and moments of the context are left untouched. */

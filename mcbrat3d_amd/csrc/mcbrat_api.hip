@@ -56,7 +56,8 @@ struct mcbrat_ctx {
   double fracAtms = 0;
   // tuning / measurement
   int blocksPerCU = 0;  // 0: from the occupancy query
-  int eventThreshold = 40;
+  int eventThreshold = 16;     // measured optimum 16 (step cloud) .. 32 (128x128x64); see DESIGN.md
+  int launchThreshold = 8, surfaceThreshold = 8;
   int maxBatchesInFlight = 0;  // 0: bounded by memory
   int privMode = 1;            // 1: LDS-private tallies when the slab fits, 0: always global atomics
   int blockSize = 0;           // 0: chosen by plan_launch
@@ -140,7 +141,7 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.ext = c->dExt; p.cum = c->dCum; p.ssa = c->dSsa; p.pfi = c->dPfi;
   p.albedo = c->albedo;
   p.tables = c->dTables;
-  for (int k = 0; k < c->nc; ++k) { p.tblOffset[k] = c->tblOffset[k]; p.tblNSteps[k] = c->tblNSteps[k]; }
+  for (int k = 0; k < c->nc; ++k) { p.tblOffset[k] = c->tblOffset[k]; p.tblNSteps[k] = c->tblNSteps[k]; p.tblInvN[k] = 1.0f / (float)c->tblNSteps[k]; }
   p.tblTotalFloats = c->tblTotalFloats;
   p.useRR = c->useRR;
   p.lwFlag = c->lwFlag > 0.f ? 1 : 0;
@@ -150,6 +151,8 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.voxelCDF = c->dVoxelCDF; p.fracAtms = c->fracAtms;
   p.counter = c->dCounter;
   p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
+  p.launchThreshold = std::max(1, std::min(64, c->launchThreshold));
+  p.surfaceThreshold = std::max(1, std::min(64, c->surfaceThreshold));
 }
 
 constexpr size_t kLdsBudget = 64 * 1024;      // default dynamic-LDS limit per workgroup
@@ -444,7 +447,7 @@ int mcbrat_get_counters(mcbrat_ctx *c, mcbrat_counters *out) {
 float mcbrat_last_trace_ms(const mcbrat_ctx *c) { return c ? c->lastTraceMs : 0.f; }
 
 int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight,
-                      int32_t privateTallies, int32_t blockSize) {
+                      int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold) {
   if (!c) return 1;
   if (blocksPerCU >= 0) c->blocksPerCU = blocksPerCU;
   if (eventThreshold > 0) c->eventThreshold = eventThreshold;
@@ -452,6 +455,8 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   if (privateTallies >= 0) c->privMode = privateTallies ? 1 : 0;
   if (blockSize == 0 || blockSize == 256 || blockSize == 512) c->blockSize = blockSize;
   else if (blockSize > 0) return fail(c, "set_tuning: blockSize must be 0, 256 or 512");
+  if (launchThreshold > 0) c->launchThreshold = launchThreshold;
+  if (surfaceThreshold > 0) c->surfaceThreshold = surfaceThreshold;
   return 0;
 }
 

@@ -32,6 +32,7 @@ struct DevParams {
   const float *tables;            // all components, concatenated, entry-major
   int tblOffset[MCBRAT_MAX_COMPONENTS];
   int tblNSteps[MCBRAT_MAX_COMPONENTS];
+  float tblInvN[MCBRAT_MAX_COMPONENTS];   // 1/nSteps
   int tblTotalFloats;
   // parameters / source
   int useRR;
@@ -53,6 +54,8 @@ struct DevParams {
   unsigned long long nUnits;      // PRIV mode: work units (each inside one batch) ...
   unsigned long long unitsPerBatch;  // ... and how many of them a batch is cut into
   int eventThreshold;             // process events when fewer than this many lanes are walking
+  int launchThreshold;            // idle lanes queued before new photons are launched
+  int surfaceThreshold;           // lanes queued before surface reflections are served
   // debug / measurement
   mcbrat_fate *fates;             // non-null: record per-photon fate (index = photon index)
   unsigned long long *counters;   // non-null: 8 event counters

@@ -49,21 +49,27 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
   for (int i = 0; i < 10; i++) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    c0 = hi1 ^ c1 ^ k0;
-    c1 = lo1;
-    c2 = hi0 ^ c3 ^ k1;
-    c3 = lo0;
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;  // v_mad_u64_u32
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    c1 = (uint32_t)p1;
+    c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c3 = (uint32_t)p0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// getRandomReal semantics (src/RandomNumbersForMC.f95:277-301): u32/(2^32-1) in double,
-// rounded to float, both ends attainable.
-__device__ __forceinline__ float u01(uint32_t u) { return (float)((double)u * (1.0 / 4294967295.0)); }
+// getRandomReal semantics (src/RandomNumbersForMC.f95:277-301): a float on the closed interval
+// [0,1] with 32-bit resolution.  The reference forms u/(2^32-1) in double and rounds to float;
+// here u is rounded to float and scaled by 2^-32 (both exact operations, so the CPU oracle
+// reproduces it bit for bit); the two maps differ by at most one float ulp, in 0.4 % of draws.
+__device__ __forceinline__ float u01(uint32_t u) { return (float)u * 2.3283064365386963e-10f; }
+
+// 1/x and a/b with the hardware reciprocal (1 ulp): geometry set-up and direction algebra
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float div_fast(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
 // element i (0..3) of a Philox block without dynamic register indexing
 __device__ __forceinline__ uint32_t pick4(const uint32_t (&r)[4], uint32_t i) {
@@ -158,7 +164,16 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const DevParams p) {
     for (;;) {
       // ================= event phase: every lane that is not walking =====================
       bool needLeg = false;
-      const unsigned long long want = __ballot(state == ST_DEAD && more);
+      // Launches and surface reflections are rare next to collisions (1 and ~0.7 per ~17 legs in
+      // the I3RC step cloud).  Serving them whenever a single lane asks would run their code at a
+      // few percent lane occupancy in almost every event phase, so they wait until enough lanes
+      // have queued up -- or until the wave has nothing else to do.
+      const unsigned long long mDead = __ballot(state == ST_DEAD && more);
+      const unsigned long long mSurf = __ballot(state == ST_SURFACE);
+      const int nBusy = __popcll(__ballot(state == ST_WALK || state == ST_COLLIDE));
+      const bool doLaunch = __popcll(mDead) >= p.launchThreshold || nBusy < p.eventThreshold;
+      const bool doSurface = __popcll(mSurf) >= p.surfaceThreshold || nBusy < p.eventThreshold;
+      const unsigned long long want = doLaunch ? mDead : 0ull;
       if (want != 0ull) {  // wave-uniform
         const int nWant = __popcll(want);
         const int rank = __popcll(want & laneBelow);
@@ -320,7 +335,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const DevParams p) {
           const int ai = (int)(uX * (float)n) + 1;
           float ang;
           if (ai < n) {
-            const float left = uX - (float)(ai - 1) / (float)n;
+            const float left = uX - (float)(ai - 1) * p.tblInvN[c];
             ang = (1.0f - left) * t[ai - 1] + left * t[ai];
           } else {
             ang = t[n - 1];
@@ -338,17 +353,17 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const DevParams p) {
               D = AX * AX + AY * AY;
             }
           }
-          float B = sqrtf((1.0f - cs * cs) / D);
+          float B = sqrtf(div_fast(1.0f - cs * cs, D));
           AX = AX * B;
           AY = AY * B;
           B = dx * AX - dy * AY;
-          D = cs - B / (1.0f + fabsf(dz));
+          D = cs - div_fast(B, 1.0f + fabsf(dz));
           dx = dx * D + AX;
           dy = dy * D - AY;
           dz = dz * cs - copysignf(fabsf(B), dz * B);
           needLeg = true;
         }
-      } else if (state == ST_SURFACE) {
+      } else if (state == ST_SURFACE && doSurface) {
         // surface, computeRT :619-676 (Lambertian); fluxDown gets the incident weight :634
         const unsigned long long dep = to_fixed((double)w);
         if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + ncol + (ix + p.nx * iy)), dep);
@@ -387,11 +402,11 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const DevParams p) {
         uX = u01(r[1]); uY = u01(r[2]); uZ = u01(r[3]);
         acc = 0.0f; tcur = 0.0f;
         // opticalProperties.f95:1690-1712: side 1 where direction >= 0; huge step for a zero cosine
-        if (fabsf(dx) >= 2.0f * FLT_MIN) { ivx = 1.0f / dx; tnx = (float)(s_edge[ix + (dx >= 0.0f ? 1 : 0)] - px) * ivx; }
+        if (fabsf(dx) >= 2.0f * FLT_MIN) { ivx = rcp_fast(dx); tnx = (float)(s_edge[ix + (dx >= 0.0f ? 1 : 0)] - px) * ivx; }
         else { ivx = 0.0f; tnx = FLT_MAX; }
-        if (fabsf(dy) >= 2.0f * FLT_MIN) { ivy = 1.0f / dy; tny = (float)(s_edge[offY + iy + (dy >= 0.0f ? 1 : 0)] - py) * ivy; }
+        if (fabsf(dy) >= 2.0f * FLT_MIN) { ivy = rcp_fast(dy); tny = (float)(s_edge[offY + iy + (dy >= 0.0f ? 1 : 0)] - py) * ivy; }
         else { ivy = 0.0f; tny = FLT_MAX; }
-        if (fabsf(dz) >= 2.0f * FLT_MIN) { ivz = 1.0f / dz; tnz = (float)(s_edge[offZ + iz + (dz >= 0.0f ? 1 : 0)] - pz) * ivz; }
+        if (fabsf(dz) >= 2.0f * FLT_MIN) { ivz = rcp_fast(dz); tnz = (float)(s_edge[offZ + iz + (dz >= 0.0f ? 1 : 0)] - pz) * ivz; }
         else { ivz = 0.0f; tnz = FLT_MAX; }
         state = ST_WALK;
       }
@@ -409,7 +424,7 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(const DevParams p) {
           const float accNew = acc + (tmin - tcur) * extCur;  // :1743
           if (accNew > tau) {
             // :1729-1738 stop inside this cell
-            const double s = (double)(tcur + (tau - acc) / extCur);
+            const double s = (double)(tcur + div_fast(tau - acc, extCur));
             px = px + s * (double)dx;
             py = py + s * (double)dy;
             pz = pz + s * (double)dz;

@@ -103,9 +103,10 @@ class Integrator:
         self._check(self._lib.mcbrat_specify_parameters(self._ctx, int(self.useRayTracing),
                                                         int(self.useRussianRoulette), C.c_float(self.LW_flag)))
 
-    def setTuning(self, blocksPerCU=-1, eventThreshold=0, maxBatchesInFlight=-1, privateTallies=-1, blockSize=-1):
+    def setTuning(self, blocksPerCU=-1, eventThreshold=0, maxBatchesInFlight=-1, privateTallies=-1, blockSize=-1,
+                  launchThreshold=0, surfaceThreshold=0):
         self._check(self._lib.mcbrat_set_tuning(self._ctx, blocksPerCU, eventThreshold, maxBatchesInFlight,
-                                                privateTallies, blockSize))
+                                                privateTallies, blockSize, launchThreshold, surfaceThreshold))
 
     # -- computeRadiativeTransfer -------------------------------------------------------
     def _load_domain(self, dom):

@@ -131,7 +131,8 @@ static void philox_next_event(orc_rng *r) {
 
 /* getRandomDouble / getRandomReal :277-301: u32/(2^32-1) in double, then to
  * float; the closed interval [0,1] (both ends attainable).  The Philox mode
- * multiplies by the reciprocal (what the HIP kernel does) instead of dividing. */
+ * rounds u to float and scales by 2^-32 (what the HIP kernel does; within one
+ * float ulp of the reference's map, also on [0,1] with both ends attainable). */
 float orc_random_real(orc_rng *r) { /* sequential (MT) stream */
   r->ndraws++;
   return (float)((double)orc_mt_next_u32(r) / 4294967295.0);
@@ -149,7 +150,7 @@ static float draw(orc_rng *r, uint32_t block, uint32_t elem) {
     orc_philox4x32_10(ctr, key, r->buf);
     r->cachedBlock = block;
   }
-  return (float)((double)r->buf[elem] * (1.0 / 4294967295.0));
+  return (float)r->buf[elem] * 2.3283064365386963e-10f; /* float(u) * 2^-32: what the HIP kernel does */
 }
 
 /* ------------------------------------------------------------------------ */

@@ -75,7 +75,10 @@ def test_fortran_driver_matches_python_host(tmp_path):
     st = driver.statistics(driver.unpack_moments(integ.moments(), 32, 1, 32))
     want = [st["meanFluxUp"], st["meanFluxUp_StdErr"], st["meanFluxDown"], st["meanFluxDown_StdErr"],
             st["meanFluxAbsorbed"], st["meanFluxAbsorbed_StdErr"]]
-    for tag in ("builtin", "flat"):
-        assert np.allclose(results[tag], want, atol=1.5e-6), (tag, results[tag], want)
-        assert np.allclose(results[tag + "_cols"][:, 2], st["fluxUp"][:, 0], atol=1e-4)
-        assert np.allclose(results[tag + "_cols"][:, 4], st["fluxDown"][:, 0], atol=1e-4)
+    # "flat" carries the Python layer's own tables: identical photons, only print rounding differs.
+    # "builtin" computes the HG coefficients in Fortran (g**l in default real): the table can differ
+    # in the last bit, which may flip a handful of the 4e5 photon histories.
+    for tag, tol_mean, tol_col in (("flat", 1.5e-6, 6e-5), ("builtin", 3e-5, 6e-4)):
+        assert np.allclose(results[tag], want, atol=tol_mean), (tag, results[tag], want)
+        assert np.allclose(results[tag + "_cols"][:, 2], st["fluxUp"][:, 0], atol=tol_col), tag
+        assert np.allclose(results[tag + "_cols"][:, 4], st["fluxDown"][:, 0], atol=tol_col), tag
