@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="i3rcStepCloud", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-photons-per-core", type=int, default=1500000)
+    ap.add_argument("--cpu-photons-per-core", type=int, default=4000000)
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -91,7 +91,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)

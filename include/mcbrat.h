@@ -123,7 +123,8 @@ int mcbrat_enable_counters(mcbrat_ctx *ctx, int32_t enable);
 int mcbrat_get_counters(mcbrat_ctx *ctx, mcbrat_counters *out);
 float mcbrat_last_trace_ms(const mcbrat_ctx *ctx);
 /* Tuning knobs (negative = leave unchanged): workgroups per CU (0 = occupancy query), number of
- * walking lanes below which a wave serves its waiting lanes, batches in flight per launch
+ * walking lanes below which a wave serves its waiting lanes (0 = choose by timing short trial
+ * launches, the default), batches in flight per launch
  * (0 = memory bound), LDS-private tallies on/off, workgroup size (0 = automatic, 256, 512), and how
  * many idle / surface lanes queue up before launches / surface reflections are served. */
 int mcbrat_set_tuning(mcbrat_ctx *ctx, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight,

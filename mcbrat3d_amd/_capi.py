@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcbrat_hip.so")
+LIB_PATH = os.environ.get("MCBRAT_LIB", os.path.join(_HERE, "libmcbrat_hip.so"))  # MCBRAT_LIB: A/B builds
 _lib = None
 
 

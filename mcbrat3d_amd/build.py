@@ -31,14 +31,15 @@ def stale():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    out = out or LIB
+    if not force and out == LIB and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + SOURCES
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + os.environ.get("MCBRAT_EXTRA_FLAGS", "").split() + ["-o", out] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

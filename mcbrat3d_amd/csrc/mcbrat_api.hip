@@ -58,6 +58,8 @@ struct mcbrat_ctx {
   int blocksPerCU = 0;  // 0: from the occupancy query
   int eventThreshold = 16;     // measured optimum 16 (step cloud) .. 32 (128x128x64); see DESIGN.md
   int launchThreshold = 8, surfaceThreshold = 8;
+  bool autoTune = true;        // pick eventThreshold by timing short trial launches (once per domain/source)
+  bool tuned = false;
   int maxBatchesInFlight = 0;  // 0: bounded by memory
   int privMode = 1;            // 1: LDS-private tallies when the slab fits, 0: always global atomics
   int blockSize = 0;           // 0: chosen by plan_launch
@@ -224,6 +226,38 @@ int check_ready(mcbrat_ctx *c) {
   return sync_tables(c);
 }
 
+
+// Times short trial launches at a few event thresholds and keeps the fastest.  The best value
+// depends on how many voxel faces a leg crosses (step cloud ~3, 128x128x64 cloud field ~14).
+int autotune(mcbrat_ctx *c, DevParams p, unsigned long long ppb, int nBatches) {
+  const unsigned long long want = 1ull << 20;  // about four photons per resident lane
+  const unsigned long long total = ppb * (unsigned long long)nBatches;
+  if (total < 4 * want) { c->tuned = true; return 0; }
+  const int nb = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)nBatches, want / std::max<unsigned long long>(1, ppb)));
+  p.total = std::min(want, ppb * (unsigned long long)nb);
+  p.fates = nullptr; p.counters = nullptr;
+  const int candidates[] = {8, 16, 24, 32, 48};
+  float best = 1e30f;
+  int bestThr = c->eventThreshold;
+  for (int thr : candidates) {
+    p.eventThreshold = thr;
+    float ms = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {  // first repetition warms caches / code
+      HIP_OK(c, hipMemsetAsync(c->dSlabs, 0, sizeof(long long) * p.slabStride * nb, c->stream));
+      HIP_OK(c, hipMemsetAsync(c->dCounter, 0, sizeof(unsigned long long), c->stream));
+      HIP_OK(c, hipEventRecord(c->ev0, c->stream));
+      if (launch_trace(c, p, false, nb)) return 1;
+      HIP_OK(c, hipEventRecord(c->ev1, c->stream));
+      HIP_OK(c, hipStreamSynchronize(c->stream));
+      HIP_OK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    }
+    if (ms < best) { best = ms; bestThr = thr; }
+  }
+  c->eventThreshold = bestThr;
+  c->tuned = true;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -292,7 +326,7 @@ int mcbrat_set_grid(mcbrat_ctx *c, int32_t nx, int32_t ny, int32_t nz, const dou
     for (int i = 0; i < nx; ++i)
       rel[(size_t)i + (size_t)nx * j] = (float)(((ye[j + 1] - ye[j]) * (xe[i + 1] - xe[i])) / ((xe[nx] - xe[0]) * (ye[ny] - ye[0])));
   if (upload(c, &c->dRelArea, rel.data(), rel.size())) return 1;
-  c->haveGrid = true; c->haveOptics = false; c->haveSource = false; c->haveLast = false;
+  c->haveGrid = true; c->haveOptics = false; c->haveSource = false; c->haveLast = false; c->tuned = false;
   if (c->dMomentsOwned) { (void)hipFree(c->dMomentsOwned); c->dMomentsOwned = nullptr; }
   c->dMoments = nullptr;
   c->slabCapacity = 0; c->finishCapacity = 0;
@@ -336,6 +370,7 @@ int mcbrat_set_optics(mcbrat_ctx *c, int32_t nc, const double *totalExt, const d
   c->tables.resize(nc); c->tblNSteps.resize(nc, 0); c->tblNEntries.resize(nc, 0);
   c->tablesDirty = true;
   c->haveOptics = true;
+  c->tuned = false;
   return 0;
 }
 
@@ -388,6 +423,7 @@ int mcbrat_set_source_solar(mcbrat_ctx *c, float solarMu, float solarAzimuthDeg)
     c->izLaunch = zi - 1;
     c->zLaunch = c->ze[zi - 1] + (t - fl) * (c->ze[zi] - c->ze[zi - 1]);
   }
+  if (c->srcKind != 0) c->tuned = false;
   c->srcKind = 0;
   c->haveSource = true;
   return 0;
@@ -400,6 +436,7 @@ int mcbrat_set_source_emission(mcbrat_ctx *c, const double *voxelWeights, double
   (void)hipSetDevice(c->device);
   if (upload(c, &c->dVoxelCDF, voxelWeights, (size_t)c->nx * c->ny * c->nz)) return 1;
   c->fracAtms = fracAtmsPower;
+  if (c->srcKind != 1) c->tuned = false;
   c->srcKind = 1;
   c->haveSource = true;
   return 0;
@@ -450,7 +487,8 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
                       int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold) {
   if (!c) return 1;
   if (blocksPerCU >= 0) c->blocksPerCU = blocksPerCU;
-  if (eventThreshold > 0) c->eventThreshold = eventThreshold;
+  if (eventThreshold > 0) { c->eventThreshold = eventThreshold; c->autoTune = false; }
+  if (eventThreshold == 0) { c->autoTune = true; c->tuned = false; }
   if (maxBatchesInFlight >= 0) c->maxBatchesInFlight = maxBatchesInFlight;
   if (privateTallies >= 0) c->privMode = privateTallies ? 1 : 0;
   if (blockSize == 0 || blockSize == 256 || blockSize == 512) c->blockSize = blockSize;
@@ -497,6 +535,11 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   p.fates = nullptr;
   p.counters = c->countersOn ? c->dEventCounters : nullptr;
   if (c->countersOn) HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 8 * sizeof(unsigned long long), c->stream));
+
+  if (c->autoTune && !c->tuned) {
+    if (autotune(c, p, (unsigned long long)ppb, (int)inFlight)) return 1;
+    p.eventThreshold = c->eventThreshold;
+  }
 
   float traceMs = 0.f;
   for (int b0 = 0; b0 < nBatches; b0 += (int)inFlight) {

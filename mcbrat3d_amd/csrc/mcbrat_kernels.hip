@@ -45,6 +45,12 @@ namespace mcbrat {
 
 constexpr unsigned kChunk = 256;  // photon ids a wave takes per global atomic (global mode)
 
+// Register budget: minimum waves per SIMD the compiler must leave room for (the second
+// argument of __launch_bounds__ on AMD).  Measured choice, see DESIGN.md section 5.
+#ifndef MCBRAT_MIN_WAVES_PER_SIMD
+#define MCBRAT_MIN_WAVES_PER_SIMD 4
+#endif
+
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
@@ -105,7 +111,7 @@ __device__ __forceinline__ int find_cdf(const double *t, int n, long long stride
 }
 
 template <int BLOCK, bool TBL_LDS, bool PRIV, bool DEBUG>
-__global__ void __launch_bounds__(BLOCK) trace_kernel(const DevParams p) {
+__global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel(const DevParams p) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   // LDS map: [edges x|y|z (double)] [private tally slab (i64), PRIV] [unit cursor, PRIV] [tables (float), TBL_LDS]
   double *s_edge = reinterpret_cast<double *>(smem_raw);
