@@ -416,7 +416,9 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         else { ivz = 0.0f; tnz = FLT_MAX; }
         state = ST_WALK;
       }
-      if (__ballot(state != ST_DEAD) == 0ull) break;  // wave-uniform: nothing alive, nothing left in this unit
+      // wave-uniform exit: nothing alive and every lane has already been refused a new photon.
+      // (A lane that died in THIS phase still has `more` set: it gets its refill attempt next time.)
+      if (__ballot(state != ST_DEAD || more) == 0ull) break;
 
       // ================= walk phase: one voxel face per iteration, branch-free ================
       // accumulateExtinctionAlongPath :1697-1814

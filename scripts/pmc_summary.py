@@ -27,3 +27,14 @@ t = out.get("trace_kernel", {})
 print(json.dumps({k: v for k, v in t.items() if not k.startswith("_")}, indent=1))
 with open(os.path.join(root, "summary.json"), "w") as fh:
     json.dump(out, fh, indent=1)
+
+# HBM-side traffic per launch of the tracing kernel, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+# WRITE_SIZE are in KB, from separate passes; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a
+# wide coalesced stream (x2); this kernel's reads are 4-8 B gathers, for which the factor is
+# uncalibrated, so both raw and corrected values are kept.
+if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+    traffic = {"fetch_kb_raw": t["FETCH_SIZE"], "write_kb": t["WRITE_SIZE"],
+               "hbm_bytes_per_launch": (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0,
+               "hbm_bytes_per_launch_uncorrected": (t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0}
+    with open(os.path.join(root, "traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
