@@ -35,7 +35,7 @@ from tests import cases  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 WORKLOADS = {
     "i3rcStepCloud": dict(make=lambda: cases.step_cloud(ssa=0.99), mu0=1.0, phi0=0.0, ppb=100000, batches=100),
-    "landsatLike128": dict(make=lambda: cases.landsat_like(), mu0=0.5, phi0=30.0, ppb=1000000, batches=10),
+    "landsatLike128": dict(make=lambda: cases.landsat_like(), mu0=0.5, phi0=30.0, ppb=1000000, batches=100),
 }
 
 

@@ -126,9 +126,11 @@ float mcbrat_last_trace_ms(const mcbrat_ctx *ctx);
  * walking lanes below which a wave serves its waiting lanes (0 = choose by timing short trial
  * launches, the default), batches in flight per launch
  * (0 = memory bound), LDS-private tallies on/off, workgroup size (0 = automatic, 256, 512), and how
- * many idle / surface lanes queue up before launches / surface reflections are served. */
+ * many idle / surface lanes queue up before launches / surface reflections are served; brickLayout:
+ * 0 dense optical grids, 1 4x4x4 bricks with unstored background bricks, 2 automatic (default). */
 int mcbrat_set_tuning(mcbrat_ctx *ctx, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight,
-                      int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold);
+                      int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold,
+                      int32_t brickLayout);
 
 /* Parity/debug: trace n photons (ids firstPhotonId..) and record what became
  * of each one.  Tallies and moments of the context are left untouched. */

@@ -30,6 +30,15 @@ struct mcbrat_ctx {
   double *dEdges = nullptr;
   float *dExt = nullptr, *dCum = nullptr, *dSsa = nullptr, *dRelArea = nullptr;
   uint16_t *dPfi = nullptr;
+  // brick layout (see mcbrat_kernels.hip locate_cell)
+  uint32_t *dBrickTable = nullptr;
+  float *dExtB = nullptr, *dCumB = nullptr, *dSsaB = nullptr, *dBgExt = nullptr, *dBgCum = nullptr, *dBgSsa = nullptr;
+  uint16_t *dPfiB = nullptr, *dBgPfi = nullptr;
+  int nbx = 0, nby = 0, nbz = 0;
+  long long nStored = 0;
+  double backgroundFraction = 0.0;  // share of bricks that are pure background
+  bool bricksBuilt = false;
+  int brickMode = 2;               // 0 dense, 1 bricks, 2 automatic
   float *dTables = nullptr;
   double *dVoxelCDF = nullptr;
   unsigned long long *dCounter = nullptr, *dEventCounters = nullptr;
@@ -128,6 +137,103 @@ int sync_tables(mcbrat_ctx *c) {
   return 0;
 }
 
+// Brick layout of the optical grids: 4x4x4 bricks; a brick is "background" when each of its cells
+// carries exactly its layer's most common record (extinction + every component's cumExt/ssa/phase
+// index).  Background bricks are not stored.  Lossless: the kernel reads the same floats either way.
+int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<float> &cu, const std::vector<float> &s,
+                 const std::vector<uint16_t> &pf, int nc) {
+  const int nx = c->nx, ny = c->ny, nz = c->nz;
+  const size_t ncol = (size_t)nx * ny, nvox = ncol * nz;
+  std::vector<float> bgExt(nz), bgCum((size_t)nc * nz), bgSsa((size_t)nc * nz);
+  std::vector<uint16_t> bgPfi((size_t)nc * nz);
+  std::vector<float> layer(ncol);
+  for (int k = 0; k < nz; ++k) {
+    std::copy(e.begin() + ncol * k, e.begin() + ncol * (k + 1), layer.begin());
+    std::sort(layer.begin(), layer.end());
+    float best = layer[0];
+    size_t bestRun = 0;
+    for (size_t i = 0; i < ncol;) {  // mode of the layer
+      size_t j = i;
+      while (j < ncol && layer[j] == layer[i]) ++j;
+      if (j - i > bestRun) { bestRun = j - i; best = layer[i]; }
+      i = j;
+    }
+    bgExt[k] = best;
+    size_t rep = ncol * k;
+    while (e[rep] != best) ++rep;  // a representative background cell of this layer
+    for (int q = 0; q < nc; ++q) {
+      bgCum[(size_t)q * nz + k] = cu[(size_t)q * nvox + rep];
+      bgSsa[(size_t)q * nz + k] = s[(size_t)q * nvox + rep];
+      bgPfi[(size_t)q * nz + k] = pf[(size_t)q * nvox + rep];
+    }
+  }
+  auto isBackground = [&](size_t v, int k) {
+    if (e[v] != bgExt[k]) return false;
+    for (int q = 0; q < nc; ++q)
+      if (cu[(size_t)q * nvox + v] != bgCum[(size_t)q * nz + k] || s[(size_t)q * nvox + v] != bgSsa[(size_t)q * nz + k] ||
+          pf[(size_t)q * nvox + v] != bgPfi[(size_t)q * nz + k])
+        return false;
+    return true;
+  };
+  const int nbx = (nx + 3) / 4, nby = (ny + 3) / 4, nbz = (nz + 3) / 4;
+  std::vector<uint32_t> table((size_t)nbx * nby * nbz, 0xffffffffu);
+  size_t stored = 0;
+  for (int bz = 0; bz < nbz; ++bz)
+    for (int by = 0; by < nby; ++by)
+      for (int bx = 0; bx < nbx; ++bx) {
+        bool bg = true;
+        for (int k = bz * 4; k < std::min(nz, bz * 4 + 4) && bg; ++k)
+          for (int j = by * 4; j < std::min(ny, by * 4 + 4) && bg; ++j)
+            for (int i = bx * 4; i < std::min(nx, bx * 4 + 4) && bg; ++i)
+              bg = isBackground((size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k), k);
+        if (!bg) table[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * bz)] = (uint32_t)(64 * stored++);
+      }
+  const size_t nS = std::max<size_t>(64 * stored, 64);
+  std::vector<float> eB(nS, 0.f), cuB(nS * nc, 0.f), sB(nS * nc, 0.f);
+  std::vector<uint16_t> pfB(nS * nc, 0);
+  for (int bz = 0; bz < nbz; ++bz)
+    for (int by = 0; by < nby; ++by)
+      for (int bx = 0; bx < nbx; ++bx) {
+        const uint32_t base = table[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * bz)];
+        if (base == 0xffffffffu) continue;
+        for (int lk = 0; lk < 4; ++lk)
+          for (int lj = 0; lj < 4; ++lj)
+            for (int li = 0; li < 4; ++li) {
+              const int i = bx * 4 + li, j = by * 4 + lj, k = bz * 4 + lk;
+              if (i >= nx || j >= ny || k >= nz) continue;
+              const size_t v = (size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k), o = base + li + 4 * (lj + 4 * lk);
+              eB[o] = e[v];
+              for (int q = 0; q < nc; ++q) {
+                cuB[(size_t)q * nS + o] = cu[(size_t)q * nvox + v];
+                sB[(size_t)q * nS + o] = s[(size_t)q * nvox + v];
+                pfB[(size_t)q * nS + o] = pf[(size_t)q * nvox + v];
+              }
+            }
+      }
+  c->nbx = nbx; c->nby = nby; c->nbz = nbz;
+  c->nStored = (long long)nS;
+  c->backgroundFraction = 1.0 - (double)stored / (double)table.size();
+  if (upload(c, &c->dBrickTable, table.data(), table.size()) || upload(c, &c->dExtB, eB.data(), eB.size()) ||
+      upload(c, &c->dCumB, cuB.data(), cuB.size()) || upload(c, &c->dSsaB, sB.data(), sB.size()) ||
+      upload(c, &c->dPfiB, pfB.data(), pfB.size()) || upload(c, &c->dBgExt, bgExt.data(), bgExt.size()) ||
+      upload(c, &c->dBgCum, bgCum.data(), bgCum.size()) || upload(c, &c->dBgSsa, bgSsa.data(), bgSsa.size()) ||
+      upload(c, &c->dBgPfi, bgPfi.data(), bgPfi.size()))
+    return 1;
+  c->bricksBuilt = true;
+  return 0;
+}
+
+// Bricks are for grids that no longer fit the cache hierarchy (32 MiB of L2 + 256 MiB Infinity
+// Cache) and are mostly background.  Measured on MI355X: at 128x128x64 (4 MiB of extinction) the
+// dense grid is as fast or 1-3 % faster, so the automatic rule only switches
+// for grids of 64 MiB and more.
+bool use_bricks(const mcbrat_ctx *c) {
+  if (!c->bricksBuilt || c->brickMode == 0) return false;
+  if (c->brickMode == 1) return true;
+  const size_t nvox = (size_t)c->nx * c->ny * c->nz;
+  return nvox * sizeof(float) >= ((size_t)64 << 20) && c->backgroundFraction >= 0.5;
+}
+
 void fill_params(mcbrat_ctx *c, DevParams &p) {
   std::memset(&p, 0, sizeof(p));
   p.nx = c->nx; p.ny = c->ny; p.nz = c->nz; p.nc = c->nc;
@@ -140,7 +246,13 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.invDX = c->xyRegular ? 1.0 / c->dX : 0.0;
   p.invDY = c->xyRegular ? 1.0 / c->dY : 0.0;
   p.edges = c->dEdges;
-  p.ext = c->dExt; p.cum = c->dCum; p.ssa = c->dSsa; p.pfi = c->dPfi;
+  if (use_bricks(c)) {
+    p.ext = c->dExtB; p.cum = c->dCumB; p.ssa = c->dSsaB; p.pfi = c->dPfiB;
+    p.brickTable = c->dBrickTable; p.nbx = c->nbx; p.nby = c->nby; p.nbz = c->nbz; p.nStored = c->nStored;
+    p.bgExt = c->dBgExt; p.bgCum = c->dBgCum; p.bgSsa = c->dBgSsa; p.bgPfi = c->dBgPfi;
+  } else {
+    p.ext = c->dExt; p.cum = c->dCum; p.ssa = c->dSsa; p.pfi = c->dPfi;
+  }
   p.albedo = c->albedo;
   p.tables = c->dTables;
   for (int k = 0; k < c->nc; ++k) { p.tblOffset[k] = c->tblOffset[k]; p.tblNSteps[k] = c->tblNSteps[k]; p.tblInvN[k] = 1.0f / (float)c->tblNSteps[k]; }
@@ -162,7 +274,7 @@ constexpr size_t kTableLdsLimit = 48 * 1024;   // tables above this stay in L2
 constexpr size_t kPrivSlabLimit = 32 * 1024;   // private tally slab above this -> global atomics
 
 struct LaunchPlan {
-  bool tblLds, priv;
+  bool tblLds, priv, brick;
   int block;
   size_t lds;
 };
@@ -173,18 +285,25 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
   const size_t tbl = sizeof(float) * (size_t)c->tblTotalFloats;
   const size_t slab = sizeof(long long) * slabStride + 16;
   L.priv = c->privMode != 0 && slab <= kPrivSlabLimit;
-  L.tblLds = tbl <= kTableLdsLimit && edges + tbl + (L.priv ? slab : 0) <= kLdsBudget;
-  if (L.priv && edges + slab + (L.tblLds ? tbl : 0) > kLdsBudget) L.priv = false;
-  L.lds = edges + (L.priv ? slab : 0) + (L.tblLds ? tbl : 0);
+  L.brick = use_bricks(c);
+  const size_t bg = L.brick ? sizeof(float) * (size_t)((c->nz + 3) & ~3) : 0;
+  L.tblLds = tbl <= kTableLdsLimit && edges + bg + tbl + (L.priv ? slab : 0) <= kLdsBudget;
+  if (L.priv && edges + bg + slab + (L.tblLds ? tbl : 0) > kLdsBudget) L.priv = false;
+  L.lds = edges + bg + (L.priv ? slab : 0) + (L.tblLds ? tbl : 0);
   L.block = c->blockSize > 0 ? c->blockSize : ((L.tblLds || L.priv) && L.lds > 16 * 1024 ? 512 : 256);
   return L;
 }
 
-template <int BLOCK, bool TBL, bool PRIV, bool DBG>
+size_t plan_launch_lds(const mcbrat_ctx *c, const LaunchPlan &L) {
+  return sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3) + (L.brick ? sizeof(float) * (size_t)((c->nz + 3) & ~3) : 0) +
+         (L.tblLds ? sizeof(float) * (size_t)c->tblTotalFloats : 0);
+}
+
+template <int BLOCK, bool TBL, bool PRIV, bool BRICK, bool DBG>
 int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   int perCU = c->blocksPerCU;
   if (perCU <= 0) {
-    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, DBG>, BLOCK, lds));
+    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG>, BLOCK, lds));
     perCU = std::max(1, std::min(perCU, 8));
   }
   unsigned long long blocks = (unsigned long long)perCU * c->numCUs;
@@ -200,21 +319,28 @@ int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
     blocks = std::min(blocks, (p.total + BLOCK - 1) / BLOCK);
   }
   const unsigned grid = (unsigned)std::max<unsigned long long>(1, blocks);
-  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, DBG>), dim3(grid), dim3(BLOCK), lds, c->stream, p);
+  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG>), dim3(grid), dim3(BLOCK), lds, c->stream, p);
   HIP_OK(c, hipGetLastError());
   return 0;
 }
 
 template <int BLOCK, bool DBG>
 int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatches) {
-  if (L.tblLds) return L.priv ? launch_trace_t<BLOCK, true, true, DBG>(c, p, L.lds, nBatches)
-                              : launch_trace_t<BLOCK, true, false, DBG>(c, p, L.lds, nBatches);
-  return L.priv ? launch_trace_t<BLOCK, false, true, DBG>(c, p, L.lds, nBatches)
-                : launch_trace_t<BLOCK, false, false, DBG>(c, p, L.lds, nBatches);
+  // instantiated combinations: private tallies (small domains) and bricks (large ones) never coincide
+  if (L.priv) return L.tblLds ? launch_trace_t<BLOCK, true, true, false, DBG>(c, p, L.lds, nBatches)
+                              : launch_trace_t<BLOCK, false, true, false, DBG>(c, p, L.lds, nBatches);
+  if (L.brick) return L.tblLds ? launch_trace_t<BLOCK, true, false, true, DBG>(c, p, L.lds, nBatches)
+                               : launch_trace_t<BLOCK, false, false, true, DBG>(c, p, L.lds, nBatches);
+  return L.tblLds ? launch_trace_t<BLOCK, true, false, false, DBG>(c, p, L.lds, nBatches)
+                  : launch_trace_t<BLOCK, false, false, false, DBG>(c, p, L.lds, nBatches);
 }
 
 int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
-  const LaunchPlan L = plan_launch(c, (size_t)p.slabStride);
+  LaunchPlan L = plan_launch(c, (size_t)p.slabStride);
+  if (L.priv && L.brick) {  // fill_params chose the brick arrays: private tallies give way
+    L.priv = false;
+    L.lds = plan_launch_lds(c, L);
+  }
   if (L.block == 512) return debug ? launch_trace_b<512, true>(c, p, L, nBatches) : launch_trace_b<512, false>(c, p, L, nBatches);
   return debug ? launch_trace_b<256, true>(c, p, L, nBatches) : launch_trace_b<256, false>(c, p, L, nBatches);
 }
@@ -287,7 +413,8 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF, c->dCounter,
-                  c->dEventCounters, c->dSlabs, c->dColVals, c->dScalVals, c->dLast, c->dMomentsOwned};
+                  c->dEventCounters, c->dSlabs, c->dColVals, c->dScalVals, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
+                  c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -364,6 +491,8 @@ int mcbrat_set_optics(mcbrat_ctx *c, int32_t nc, const double *totalExt, const d
   if (upload(c, &c->dExt, e.data(), e.size()) || upload(c, &c->dCum, cu.data(), cu.size()) ||
       upload(c, &c->dSsa, s.data(), s.size()) || upload(c, &c->dPfi, pf.data(), pf.size()))
     return 1;
+  c->bricksBuilt = false;
+  if (build_bricks(c, e, cu, s, pf, nc)) return 1;
   c->nc = nc;
   c->albedo = (float)albedo;
   c->maxPfi = maxPfi;
@@ -484,7 +613,8 @@ int mcbrat_get_counters(mcbrat_ctx *c, mcbrat_counters *out) {
 float mcbrat_last_trace_ms(const mcbrat_ctx *c) { return c ? c->lastTraceMs : 0.f; }
 
 int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight,
-                      int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold) {
+                      int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold,
+                      int32_t brickLayout) {
   if (!c) return 1;
   if (blocksPerCU >= 0) c->blocksPerCU = blocksPerCU;
   if (eventThreshold > 0) { c->eventThreshold = eventThreshold; c->autoTune = false; }
@@ -495,6 +625,7 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   else if (blockSize > 0) return fail(c, "set_tuning: blockSize must be 0, 256 or 512");
   if (launchThreshold > 0) c->launchThreshold = launchThreshold;
   if (surfaceThreshold > 0) c->surfaceThreshold = surfaceThreshold;
+  if (brickLayout >= 0 && brickLayout <= 2) { if (brickLayout != c->brickMode) c->tuned = false; c->brickMode = brickLayout; }
   return 0;
 }
 

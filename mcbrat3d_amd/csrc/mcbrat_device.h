@@ -12,7 +12,7 @@ constexpr double kTallyScale = 4294967296.0;  // tallies are signed 64-bit fixed
 constexpr double kTallyInv = 1.0 / 4294967296.0;
 
 // States of a lane in the tracing loop.
-enum : int { ST_DEAD = 0, ST_WALK = 1, ST_COLLIDE = 2, ST_SURFACE = 3 };
+enum : int { ST_DEAD = 0, ST_WALK = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_TOP = 4 };
 
 struct DevParams {
   // grid (set_grid)
@@ -28,6 +28,14 @@ struct DevParams {
   const float *ssa;               // [nc][nvox]
   const uint16_t *pfi;            // [nc][nvox] 0-based entry
   float albedo;
+  // brick layout of the optics (large, mostly-background domains): ext/cum/ssa/pfi then hold the
+  // STORED bricks only (64 cells each, [component][nStored]); background cells use bg* [component][nz]
+  const uint32_t *brickTable;     // [nbz][nby][nbx] offset of the brick's 64 cells, 0xffffffff = background
+  int nbx, nby, nbz;
+  long long nStored;              // stored cells = 64 * stored bricks
+  const float *bgExt;             // [nz]
+  const float *bgCum, *bgSsa;     // [nc][nz]
+  const uint16_t *bgPfi;          // [nc][nz]
   // inverse phase-function tables (set_inverse_table)
   const float *tables;            // all components, concatenated, entry-major
   int tblOffset[MCBRAT_MAX_COMPONENTS];

@@ -110,17 +110,48 @@ __device__ __forceinline__ int find_cdf(const double *t, int n, long long stride
   return hi;
 }
 
-template <int BLOCK, bool TBL_LDS, bool PRIV, bool DEBUG>
+// Optical-property lookup.  Dense: one gather from the [nz][ny][nx] grid.  BRICK: the grid is cut
+// into 4x4x4 bricks; a brick whose 64 cells all equal their layer's background value (clear air:
+// most of a cloud scene) has no storage -- its cells read the per-layer background from LDS --
+// and only the other bricks are stored, 64 cells each.  The brick table (4 B per 64 cells) and the
+// stored bricks are a fraction of the dense grid, so the walk's working set fits the XCD's 4 MiB
+// L2 instead of thrashing it (L2 hit rate 72 % -> measured there).
+struct CellRef {
+  int dense;   // dense cell index (tallies, and optics when !BRICK)
+  int stored;  // BRICK: index into the stored-brick arrays, or -1 for a background cell
+};
+
+template <bool BRICK>
+__device__ __forceinline__ CellRef locate_cell(const DevParams &p, int ix, int iy, int iz) {
+  CellRef r;
+  r.dense = ix + p.nx * (iy + p.ny * iz);
+  r.stored = -1;
+  if (BRICK) {
+    const uint32_t base = p.brickTable[(ix >> 2) + p.nbx * ((iy >> 2) + p.nby * (iz >> 2))];
+    if (base != 0xffffffffu) r.stored = (int)(base + (uint32_t)((ix & 3) + 4 * ((iy & 3) + 4 * (iz & 3))));
+  }
+  return r;
+}
+
+template <bool BRICK>
+__device__ __forceinline__ float load_ext(const DevParams &p, const float *s_bgExt, const CellRef &r, int iz) {
+  if (!BRICK) return p.ext[r.dense];
+  return r.stored >= 0 ? p.ext[r.stored] : s_bgExt[iz];
+}
+
+template <int BLOCK, bool TBL_LDS, bool PRIV, bool BRICK, bool DEBUG>
 __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel(const DevParams p) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  // LDS map: [edges x|y|z (double)] [private tally slab (i64), PRIV] [unit cursor, PRIV] [tables (float), TBL_LDS]
+  // LDS map: [edges x|y|z (double)] [private tally slab (i64), PRIV] [unit cursor, PRIV]
+  //          [background extinction per layer, BRICK] [tables (float), TBL_LDS]
   double *s_edge = reinterpret_cast<double *>(smem_raw);
   const int nEdges = p.nx + p.ny + p.nz + 3;
   const int ncol = p.nx * p.ny;
   const int slabLen = PRIV ? (int)p.slabStride : 0;
   long long *s_slab = reinterpret_cast<long long *>(s_edge + nEdges);
   unsigned *s_cursor = reinterpret_cast<unsigned *>(s_slab + slabLen);
-  float *s_tbl = reinterpret_cast<float *>(s_cursor + (PRIV ? 4 : 0));
+  float *s_bgExt = reinterpret_cast<float *>(s_cursor + (PRIV ? 4 : 0));  // BRICK: background extinction per layer
+  float *s_tbl = s_bgExt + (BRICK ? ((p.nz + 3) & ~3) : 0);
   for (int i = threadIdx.x; i < nEdges; i += BLOCK) s_edge[i] = p.edges[i];
   if (TBL_LDS)
     for (int i = threadIdx.x; i < p.tblTotalFloats; i += BLOCK) s_tbl[i] = p.tables[i];
@@ -128,6 +159,8 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
     for (int i = threadIdx.x; i < slabLen; i += BLOCK) s_slab[i] = 0;
     if (threadIdx.x == 0) s_cursor[0] = 0;
   }
+  if (BRICK)
+    for (int i = threadIdx.x; i < p.nz; i += BLOCK) s_bgExt[i] = p.bgExt[i];
   __syncthreads();
   const float *__restrict__ tbl = TBL_LDS ? s_tbl : p.tables;
   const int offY = p.nx + 1, offZ = p.nx + p.ny + 2;  // edge table offsets
@@ -176,7 +209,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
       // have queued up -- or until the wave has nothing else to do.
       const unsigned long long mDead = __ballot(state == ST_DEAD && more);
       const unsigned long long mSurf = __ballot(state == ST_SURFACE);
-      const int nBusy = __popcll(__ballot(state == ST_WALK || state == ST_COLLIDE));
+      const int nBusy = __popcll(__ballot(state == ST_WALK || state == ST_COLLIDE || state == ST_TOP));
       const bool doLaunch = __popcll(mDead) >= p.launchThreshold || nBusy < p.eventThreshold;
       const bool doSurface = __popcll(mSurf) >= p.surfaceThreshold || nBusy < p.eventThreshold;
       const unsigned long long want = doLaunch ? mDead : 0ull;
@@ -287,7 +320,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
               iz = min((int)fl, p.nz - 1);
               pz = s_edge[offZ + iz] + (t - fl) * (s_edge[offZ + iz + 1] - s_edge[offZ + iz]);
             }
-            extCur = p.ext[ix + p.nx * (iy + p.ny * iz)];
+            extCur = load_ext<BRICK>(p, s_bgExt, locate_cell<BRICK>(p, ix, iy, iz), iz);
             if (p.lwFlag && pz > 0.0) {  // :504-508 emission counts as negative absorption
               const int cell = ix + p.nx * (iy + p.ny * iz);
               if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + cell), to_fixed(-1.0));
@@ -300,13 +333,35 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         }
       }
       // ---- deferred events -------------------------------------------------------------
-      if (state == ST_COLLIDE) {
+      if (state == ST_TOP) {
+        // out the top, computeRT :573-617: tally and free the lane
+        const unsigned long long dep = to_fixed((double)w);
+        if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + (ix + p.nx * iy)), dep);
+        else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + (ix + p.nx * iy)), dep);
+        if (DEBUG) {
+          cTop++;
+          if (p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{0, ix + 1, iy + 1, p.nz + 1, nScat, nLegs, w};
+        }
+        state = ST_DEAD;
+      } else if (state == ST_COLLIDE) {
         // scattering event, computeRT :703-821 (the zero-extinction back-step :728-754 cannot
         // arise: a collision is only declared inside a cell with extinction > 0)
+        {  // opticalProperties.f95:1729-1738: the point inside the cell where tau is used up
+          const double s = (double)(tcur + div_fast(tau - acc, extCur));
+          px = px + s * (double)dx;
+          py = py + s * (double)dy;
+          pz = pz + s * (double)dz;
+        }
         nScat++;
         if (DEBUG) cColl++;
-        const int cell = ix + p.nx * (iy + p.ny * iz);
-        const long long nvox = (long long)ncol * p.nz;
+        const CellRef cr = locate_cell<BRICK>(p, ix, iy, iz);
+        const int cell = cr.dense;
+        // optics of this cell: dense grid, stored brick, or the layer's background record
+        const long long nvox = BRICK ? (cr.stored >= 0 ? p.nStored : (long long)p.nz) : (long long)ncol * p.nz;
+        const int oc = BRICK ? (cr.stored >= 0 ? cr.stored : iz) : cell;
+        const float *cumA = (BRICK && cr.stored < 0) ? p.bgCum : p.cum;
+        const float *ssaA = (BRICK && cr.stored < 0) ? p.bgSsa : p.ssa;
+        const uint16_t *pfiA = (BRICK && cr.stored < 0) ? p.bgPfi : p.pfi;
         uint32_t r1[4] = {0u, 0u, 0u, 0u};
         bool haveR1 = false;
         int c = 0;  // component pick :759-760 (findIndex over [0, cumExt(:)])
@@ -315,9 +370,9 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           haveR1 = true;
           const float uA = u01(r1[0]);
           for (int k = 0; k < p.nc - 1; k++)
-            if (uA >= p.cum[(long long)k * nvox + cell]) c = k + 1;
+            if (uA >= cumA[(long long)k * nvox + oc]) c = k + 1;
         }
-        const float ssa = p.ssa[(long long)c * nvox + cell];
+        const float ssa = ssaA[(long long)c * nvox + oc];
         if (ssa < 1.0f) {  // absorption :765-771
           const unsigned long long dep = to_fixed((double)w * (1.0 - (double)ssa));
           if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + cell), dep);
@@ -335,7 +390,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           state = ST_DEAD;
         } else {
           // computeScatteringAngle :1594-1621 (table point count N, floor-type lookup as written)
-          const int pf = p.pfi[(long long)c * nvox + cell];
+          const int pf = pfiA[(long long)c * nvox + oc];
           const int n = p.tblNSteps[c];
           const float *t = tbl + p.tblOffset[c] + (long long)pf * n;
           const int ai = (int)(uX * (float)n) + 1;
@@ -371,6 +426,10 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         }
       } else if (state == ST_SURFACE && doSurface) {
         // surface, computeRT :619-676 (Lambertian); fluxDown gets the incident weight :634
+        px = px + (double)tcur * (double)dx;  // where the leg met z0 (:1809-1812)
+        py = py + (double)tcur * (double)dy;
+        pz = p.zSurf;
+        iz = 0;
         const unsigned long long dep = to_fixed((double)w);
         if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + ncol + (ix + p.nx * iy)), dep);
         else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + ncol + (ix + p.nx * iy)), dep);
@@ -431,12 +490,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           if (tnz < tmin) { tmin = tnz; ax = 2; }
           const float accNew = acc + (tmin - tcur) * extCur;  // :1743
           if (accNew > tau) {
-            // :1729-1738 stop inside this cell
-            const double s = (double)(tcur + div_fast(tau - acc, extCur));
-            px = px + s * (double)dx;
-            py = py + s * (double)dy;
-            pz = pz + s * (double)dz;
-            state = ST_COLLIDE;
+            state = ST_COLLIDE;  // :1729-1738: the stop point inside this cell is resolved in the event phase
           } else {
             acc = accNew;
             tcur = tmin;
@@ -446,22 +500,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
             int iAx = (ax == 0 ? ix : (ax == 1 ? iy : iz)) + (fwd ? 1 : -1);
             const int nAx = ax == 0 ? p.nx : (ax == 1 ? p.ny : p.nz);
             if (ax == 2 && (iAx >= nAx || iAx < 0)) {
-              if (iAx >= nAx) {  // out the top :1801-1804, computeRT :573-617
-                const unsigned long long dep = to_fixed((double)w);
-                if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + (ix + p.nx * iy)), dep);
-                else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + (ix + p.nx * iy)), dep);
-                if (DEBUG) {
-                  cTop++;
-                  if (p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{0, ix + 1, iy + 1, p.nz + 1, nScat, nLegs, w};
-                }
-                state = ST_DEAD;
-              } else {  // hit the bottom :1809-1812, computeRT :619-633
-                px = px + (double)tmin * (double)dx;
-                py = py + (double)tmin * (double)dy;
-                pz = p.zSurf;
-                iz = 0;
-                state = ST_SURFACE;
-              }
+              state = iAx < 0 ? ST_SURFACE : ST_TOP;  // :1801-1812; tallied in the event phase
             } else {
               if (iAx >= nAx) {  // periodic x / y :1782-1796: continue in the next image of the domain
                 iAx = 0;
@@ -475,7 +514,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
               const float tNew = (float)(edge - origin) * (ax == 0 ? ivx : (ax == 1 ? ivy : ivz));
               tnx = ax == 0 ? tNew : tnx; tny = ax == 1 ? tNew : tny; tnz = ax == 2 ? tNew : tnz;
               ix = ax == 0 ? iAx : ix; iy = ax == 1 ? iAx : iy; iz = ax == 2 ? iAx : iz;
-              extCur = p.ext[ix + p.nx * (iy + p.ny * iz)];
+              extCur = load_ext<BRICK>(p, s_bgExt, locate_cell<BRICK>(p, ix, iy, iz), iz);
             }
           }
         }

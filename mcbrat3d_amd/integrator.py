@@ -104,9 +104,9 @@ class Integrator:
                                                         int(self.useRussianRoulette), C.c_float(self.LW_flag)))
 
     def setTuning(self, blocksPerCU=-1, eventThreshold=0, maxBatchesInFlight=-1, privateTallies=-1, blockSize=-1,
-                  launchThreshold=0, surfaceThreshold=0):
+                  launchThreshold=0, surfaceThreshold=0, brickLayout=-1):
         self._check(self._lib.mcbrat_set_tuning(self._ctx, blocksPerCU, eventThreshold, maxBatchesInFlight,
-                                                privateTallies, blockSize, launchThreshold, surfaceThreshold))
+                                                privateTallies, blockSize, launchThreshold, surfaceThreshold, brickLayout))
 
     # -- computeRadiativeTransfer -------------------------------------------------------
     def _load_domain(self, dom):

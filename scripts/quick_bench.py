@@ -18,14 +18,17 @@ def main():
     ap.add_argument("--thr", type=int, nargs="*", default=[40])
     ap.add_argument("--bpc", type=int, nargs="*", default=[0])
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--ssa", type=float, default=0.99)
+    ap.add_argument("--inflight", type=int, nargs="*", default=[-1])
     ap.add_argument("--lthr", type=int, nargs="*", default=[0])
     ap.add_argument("--sthr", type=int, nargs="*", default=[0])
     ap.add_argument("--priv", type=int, nargs="*", default=[-1])
+    ap.add_argument("--brick", type=int, nargs="*", default=[-1])
     ap.add_argument("--block", type=int, nargs="*", default=[-1])
     a = ap.parse_args()
     import mcbrat3d_amd as M
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
-    case = cases.step_cloud(0.99) if a.case == "step" else cases.landsat_like()
+    case = cases.step_cloud(a.ssa) if a.case == "step" else cases.landsat_like(ssa_cloud=a.ssa)
     mu0, phi0 = (1.0, 0.0) if a.case == "step" else (0.5, 30.0)
     t0 = time.time()
     dom = cases.product_domain(case)
@@ -34,9 +37,10 @@ def main():
     photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
     print("setup %.2fs" % (time.time() - t0), flush=True)
     import itertools
-    for bpc, priv, block, thr, lthr, sthr in itertools.product(a.bpc, a.priv, a.block, a.thr, a.lthr, a.sthr):
+    for bpc, priv, block, thr, lthr, sthr, brick in itertools.product(a.bpc, a.priv, a.block, a.thr, a.lthr, a.sthr, a.brick):
+      for inflight in a.inflight:
         if True:
-            integ.setTuning(blocksPerCU=bpc, eventThreshold=thr, privateTallies=priv, blockSize=block, launchThreshold=lthr, surfaceThreshold=sthr)
+            integ.setTuning(blocksPerCU=bpc, eventThreshold=thr, privateTallies=priv, blockSize=block, launchThreshold=lthr, surfaceThreshold=sthr, brickLayout=brick, maxBatchesInFlight=inflight)
             rates = []
             for r in range(a.reps):
                 rng = new_RandomNumberSequence(1234 + r)
@@ -46,8 +50,8 @@ def main():
                 dt = time.time() - t
                 rates.append((n / dt, n / (integ.lastTraceMs() * 1e-3)))
             res = integ.reportResults()
-            print("case=%s bpc=%d priv=%d block=%d thr=%d lthr=%d sthr=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
-                a.case, bpc, priv, block, thr, lthr, sthr, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
+            print("case=%s bpc=%d priv=%d block=%d thr=%d lthr=%d sthr=%d brick=%d inflight=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
+                a.case, bpc, priv, block, thr, lthr, sthr, brick, inflight, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
                 res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"]), flush=True)
 
 

@@ -135,3 +135,26 @@ def test_error_paths_through_the_abi(M):
     with pytest.raises(M.McbratError, match="Didn't process any photons"):
         integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(1), photons, 1000)
     integ.finalize()
+
+
+def test_brick_layout_is_lossless(M):
+    """4x4x4 bricks with unstored background bricks vs the dense grids: the kernel must read the
+    same floats, so the moment arrays are bitwise equal -- on a cloud field with a large clear
+    fraction (two components) and on a domain without any background (all bricks stored, with
+    ragged brick edges: 30 x 3 x 13 cells)."""
+    case = cases.landsat_like(n=48, nz=24, n_entries=6)
+    _, _, _, a = _run(M, case, 0.5, 30.0, 30000, 4, tuning=dict(brickLayout=0, eventThreshold=32))
+    _, _, _, b = _run(M, case, 0.5, 30.0, 30000, 4, tuning=dict(brickLayout=1, eventThreshold=32))
+    assert np.array_equal(a, b)
+    rng = np.random.default_rng(5)
+    ext = rng.uniform(0.5, 40.0, (30, 3, 13))
+    odd = dict(name="odd", xe=0.01 * np.arange(31), ye=0.02 * np.arange(4), ze=np.concatenate([[0.0], np.cumsum(rng.uniform(0.01, 0.03, 13))]),
+               components=[dict(ext=ext, ssa=rng.uniform(0.8, 1.0, ext.shape), pfIndex=rng.integers(1, 4, ext.shape).astype(np.int32),
+                                legendre=[cases.hg_legendre(g, 16) for g in (0.6, 0.75, 0.85)])], albedo=0.3)
+    _, _, _, a = _run(M, odd, 0.7, 120.0, 20000, 3, tuning=dict(brickLayout=0, privateTallies=0))
+    _, _, _, b = _run(M, odd, 0.7, 120.0, 20000, 3, tuning=dict(brickLayout=1, privateTallies=0))
+    assert np.array_equal(a, b)
+    ref = _oracle(odd, 0.7, 120.0, 20000)
+    _, _, last, _ = _run(M, odd, 0.7, 120.0, 20000, 1, tuning=dict(brickLayout=1))
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert abs(last[k] - ref[k]) < 2e-3, (k, last[k], ref[k])
