@@ -128,3 +128,9 @@ def product_domain(case):
                                 zLevelBase=comp.get("zLevelBase", 1))
     dom.getOpticalPropertiesByComponent()
     return dom
+
+
+def radar_like(n=128, nz=64, seed=20240602):
+    """Config 5: optically thick, strongly absorbing 3-D field: as landsat_like with a
+    heavier tail (sigma 1.2, tau up to ~100+) and omega0 = 0.9, so that Russian roulette is played often."""
+    return landsat_like(n=n, nz=nz, sigma=1.2, mean_tau=20.0, seed=seed, ssa_cloud=0.9, rayleigh=True)

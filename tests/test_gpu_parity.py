@@ -214,3 +214,81 @@ def test_plane_parallel_plumbing(M):
         if ssa == 1.0:
             assert res["meanFluxAbsorbed"] == 0.0 and abs(res["meanFluxUp"] + res["meanFluxDown"] - 1.0) < 1e-6
         integ.finalize()
+
+
+def test_radar_like_roulette_heavy(M):
+    """Config 5 (reduced to 64x64x32 for the oracle's sake): tau up to ~100, omega0 = 0.9 -- most photons
+    end at Russian roulette.  Per-photon and per-batch parity, and roulette's weight bookkeeping:
+    kills and survivals balance statistically (:805-811)."""
+    from oracle import oracle as O
+    n = 40000
+    case = cases.radar_like(n=64, nz=32)
+    dom, integ, photons, rng = _setup(M, case, 0.7, 200.0)
+    got = integ.traceFates(dom, rng, photons, n)
+    cnt = integ.counters()
+    P = cases.oracle_problem(case)
+    ref = O.compute_rt(P, O.solar_source(0.7, 200.0), O.philox_rng(SEED, 0), n, want_fates=True)
+    rf = ref["fates"]
+    same = (got["fate"] == rf["fate"]) & (got["ix"] == rf["ix"]) & (got["iy"] == rf["iy"]) & \
+        (got["nScatter"] == rf["nScatter"]) & (np.abs(got["weight"] - rf["weight"]) <= 1e-6)
+    assert same.mean() > 0.99, "only %.4f of photon histories identical" % same.mean()
+    assert (rf["fate"] == 2).mean() > 0.15  # roulette really is the common ending here
+    for k in ("rouletteKills", "rouletteSurvivals", "collisions", "legs"):
+        assert abs(cnt[k] - ref["counters"][k]) <= 0.01 * ref["counters"][k] + 5, (k, cnt[k], ref["counters"][k])
+    integ.computeRadiativeTransfer(dom, rng, photons, n)
+    res = integ.reportResults()
+    mu, md, ma, _ = O.report_means(P, O.normalize(P, n, ref))
+    for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
+        assert abs(g - r) < 6e-3 * max(r, 0.05), (g, r)
+    assert abs(res["meanFluxUp"] + res["meanFluxDown"] + res["meanFluxAbsorbed"] - 1.0) < 0.02
+
+
+def test_broadband_thermal_loop(M):
+    """Config 4's mechanism: a loop over wavelength domains (8-12 um, isothermal 20x20x20 layer over
+    a warmer surface), photons split by emitted power, one moment array for the whole spectrum.
+    Oracle side: the same loop with the oracle's emission weighting and photon loop, same photon
+    ids.  Parity unpinned for the driver-level pieces (restated from source text)."""
+    from mcbrat3d_amd import broadband, driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    from oracle import oracle as O
+    lambdas = [8.0, 9.0, 10.0, 11.0, 12.0]
+    ppb, nb = 4000, 10
+    doms, cases_l = [], []
+    for lam in lambdas:
+        c = cases.homog_lw(n=20, lam=lam, ext=5.0 + 0.5 * (lam - 8.0), ssa=0.5)
+        cases_l.append(c)
+        doms.append(cases.product_domain(c))
+    integ = M.new_Integrator(doms[0])
+    integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True, LW_flag=1.0)
+    integ.resetMoments()
+    rng = new_RandomNumberSequence(SEED)
+    counts, flux = broadband.run_thermal(integ, doms, 300.0, ppb, nb, rng, seed=3)
+    assert counts.sum() == ppb * nb and rng.nextPhotonId == ppb * nb
+    st = driver.statistics(driver.unpack_moments(integ.moments(), 20, 20, 20), solarFlux=flux)
+
+    # oracle: same widths, fluxes, CDF; same photons per wavelength
+    widths = broadband.spectral_widths(lambdas)
+    assert np.allclose(widths, [1.0, 1.0, 1.0, 1.0, 1.0])
+    fl, srcs, probs = [], [], []
+    for c, dl in zip(cases_l, widths):
+        P = cases.oracle_problem(c, nsteps=9001, lw_flag=1.0)
+        vw, frac, f = O.emission_weighting(P, c["temps"].transpose(2, 1, 0).reshape(-1), c["lambda_um"], 300.0, dl)
+        fl.append(f); srcs.append(O.EmissionSource(vw, frac)); probs.append(P)
+    cdf, total = broadband.emitted_flux_cdf(fl)
+    assert total == pytest.approx(flux, rel=1e-12) and cdf[-1] == 1.0 and np.all(np.diff(cdf) > 0)
+    # photon split follows the power CDF (multinomial): 5-sigma check per wavelength
+    p = np.diff(np.concatenate([[0.0], cdf]))
+    assert np.all(np.abs(counts - p * ppb * nb) < 5 * np.sqrt(p * (1 - p) * ppb * nb) + 1)
+    batches, first = [], 0
+    for P, src, n in zip(probs, srcs, counts):
+        left = int(n)
+        while left > 0:
+            k = min(ppb, left)
+            r = O.compute_radiative_transfer(P, src, O.philox_rng(SEED, first), k)
+            batches.append((k, np.array([r["meanFluxUp"], r["meanFluxDown"], r["meanFluxAbsorbed"]], np.float64)))
+            first += k; left -= k
+    mean, err = O.batch_statistics(batches, solar_flux=total)
+    got = np.array([st["meanFluxUp"], st["meanFluxDown"], st["meanFluxAbsorbed"]])
+    assert np.all(np.abs(got - mean) < 2e-3 * total), (got, mean)
+    assert st["batches"] == len(batches)
+    assert st["meanFluxAbsorbed"] < 0 < st["meanFluxUp"]  # the layer cools: it emits more than it absorbs
