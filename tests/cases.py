@@ -79,6 +79,8 @@ def landsat_like(n=128, nz=64, sigma=0.8, mean_tau=10.0, seed=20240601, ssa_clou
     for i in range(n):
         for j in range(n):
             k0, k1 = base, min(base + thick[i, j], nz - 2)
+            if k1 <= k0:
+                continue
             depth = ze[k1] - ze[k0]
             ext[i, j, k0:k1] = tau[i, j] / depth
             # effective radius grows with height in the cloud: entry index by layer + column offset

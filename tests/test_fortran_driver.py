@@ -82,3 +82,43 @@ def test_fortran_driver_matches_python_host(tmp_path):
         assert np.allclose(results[tag], want, atol=tol_mean), (tag, results[tag], want)
         assert np.allclose(results[tag + "_cols"][:, 2], st["fluxUp"][:, 0], atol=tol_col), tag
         assert np.allclose(results[tag + "_cols"][:, 4], st["fluxDown"][:, 0], atol=tol_col), tag
+
+
+@pytest.mark.gpu
+def test_python_driver_from_dom_file(tmp_path):
+    """Reference-format inputs and outputs around the hot path: a .dom NetCDF domain file in, the
+    driver's namelists, NetCDF + ASCII result files out; numbers equal the direct API run."""
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd import driver, driver_cli, ncio
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    from scipy.io import netcdf_file
+    case = cases.landsat_like(n=32, nz=16, n_entries=5)
+    dom = cases.product_domain(case)
+    domfile = ncio.write_Domain(dom, str(tmp_path / "scene.dom"))
+    nml = tmp_path / "run.nml"
+    nml.write_text("""&radiativeTransfer
+  solarMu = 0.5, solarAzimuth = 30.0 /
+&monteCarlo
+  numPhotonsPerBatch = 20000, numBatches = 6, iseed = 11, nPhaseIntervals = 9001 /
+&algorithms /
+&output
+  reportVolumeAbsorption = .true., reportAbsorptionProfile = .true. /
+&fileNames
+  physDomainFile = "%s", outputNetcdfFile = "%s", outputFluxFile = "%s" /
+""" % (domfile, tmp_path / "out.nc", tmp_path / "flux.out"))
+    st = driver_cli.main([str(nml)])
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001)
+    photons = M.new_PhotonStream(0.5, 30.0, numberOfPhotons=10 ** 9)
+    integ.resetMoments()
+    integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(11), photons, 20000, 6)
+    want = driver.statistics(driver.unpack_moments(integ.moments(), 32, 32, 16))
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed", "fluxUp", "absorbedVolume", "absorbedProfile_StdErr"):
+        assert np.array_equal(st[k], want[k]), k
+    f = netcdf_file(str(tmp_path / "out.nc"), "r", mmap=False)
+    assert np.allclose(f.variables["fluxUp"][:].T, want["fluxUp"], rtol=1e-6)
+    assert np.allclose(f.variables["absorbedVolume"][:].transpose(2, 1, 0), want["absorbedVolume"], rtol=1e-6, atol=1e-12)
+    assert f.Total_number_of_photons == 120000 and f.Number_of_batches == 6
+    f.close()
+    rows = [l.split() for l in open(tmp_path / "flux.out") if not l.startswith("!")]
+    assert len(rows) == 32 * 32
