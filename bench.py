@@ -205,7 +205,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_photon": bpp, "kernel": "trace_kernel", "kernel_ms_per_launch": launch_ms,
-                         "events_per_photon": {k: v / per_step for k, v in cnt.items()},
+                         "events_per_photon": {k: v / per_step for k, v in cnt.items() if k in ("legs", "crossings", "collisions", "absorbEvents", "topExits", "surfaceHits", "rouletteKills", "rouletteSurvivals")},
+                         "lanes_per_walk_iteration": cnt["walkLanes"] / max(1, cnt["walkIterations"]),
+                         "lanes_per_event_phase": cnt["eventLanes"] / max(1, cnt["eventPhases"]),
                          "note": "working set is cache resident; the path is latency/VALU bound (DESIGN.md)"},
         }
         if not a.no_cpu_baseline:

@@ -44,6 +44,9 @@ typedef struct {
 typedef struct {
   int64_t legs, crossings, collisions, absorbEvents, topExits, surfaceHits,
           rouletteKills, rouletteSurvivals;
+  /* wave-level loop statistics: iterations of the walk loop and lanes walking in them, event
+   * phases and lanes served in them, phases that launched photons / reflected off the surface */
+  int64_t walkIterations, walkLanes, eventPhases, eventLanes, launchPhases, surfacePhases;
 } mcbrat_counters;
 
 int mcbrat_abi_version(void);

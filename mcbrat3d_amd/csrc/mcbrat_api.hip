@@ -401,7 +401,7 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipMalloc((void **)&c->dCounter, sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc((void **)&c->dEventCounters, 8 * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc((void **)&c->dEventCounters, 16 * sizeof(unsigned long long)) != hipSuccess) {
     delete c;
     return nullptr;
   }
@@ -665,7 +665,7 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   p.ppb = (unsigned long long)ppb;
   p.fates = nullptr;
   p.counters = c->countersOn ? c->dEventCounters : nullptr;
-  if (c->countersOn) HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 8 * sizeof(unsigned long long), c->stream));
+  if (c->countersOn) HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 16 * sizeof(unsigned long long), c->stream));
 
   if (c->autoTune && !c->tuned) {
     if (autotune(c, p, (unsigned long long)ppb, (int)inFlight)) return 1;
@@ -700,10 +700,11 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   }
   c->lastTraceMs = traceMs;
   if (c->countersOn) {
-    unsigned long long h[8];
+    unsigned long long h[16];
     HIP_OK(c, hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost));
     c->lastCounters = mcbrat_counters{(int64_t)h[0], (int64_t)h[1], (int64_t)h[2], (int64_t)h[3],
-                                      (int64_t)h[4], (int64_t)h[5], (int64_t)h[6], (int64_t)h[7]};
+                                      (int64_t)h[4], (int64_t)h[5], (int64_t)h[6], (int64_t)h[7],
+                                      (int64_t)h[8], (int64_t)h[9], (int64_t)h[10], (int64_t)h[11], (int64_t)h[12], (int64_t)h[13]};
   }
   c->haveLast = true;
   if (numPhotonsProcessed) *numPhotonsProcessed = ppb * (int64_t)nBatches;
@@ -744,7 +745,7 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
   HIP_OK(c, hipMemsetAsync(scratch, 0, sizeof(long long) * slabStride, c->stream));
   HIP_OK(c, hipMemsetAsync(dF, 0xff, sizeof(mcbrat_fate) * (size_t)n, c->stream));
   HIP_OK(c, hipMemsetAsync(c->dCounter, 0, sizeof(unsigned long long), c->stream));
-  HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 8 * sizeof(unsigned long long), c->stream));
+  HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 16 * sizeof(unsigned long long), c->stream));
   DevParams p;
   fill_params(c, p);
   p.seedLo = (uint32_t)seed; p.seedHi = (uint32_t)(seed >> 32);
@@ -755,11 +756,12 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
   if (!rc) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(fates, dF, sizeof(mcbrat_fate) * (size_t)n, hipMemcpyDeviceToHost);
-    unsigned long long h[8];
+    unsigned long long h[16];
     if (e == hipSuccess) e = hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(c, std::string("trace_fates: ") + hipGetErrorString(e));
     else c->lastCounters = mcbrat_counters{(int64_t)h[0], (int64_t)h[1], (int64_t)h[2], (int64_t)h[3],
-                                           (int64_t)h[4], (int64_t)h[5], (int64_t)h[6], (int64_t)h[7]};
+                                           (int64_t)h[4], (int64_t)h[5], (int64_t)h[6], (int64_t)h[7],
+                                           (int64_t)h[8], (int64_t)h[9], (int64_t)h[10], (int64_t)h[11], (int64_t)h[12], (int64_t)h[13]};
   }
   (void)hipFree(scratch);
   (void)hipFree(dF);

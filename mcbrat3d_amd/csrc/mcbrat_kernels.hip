@@ -77,6 +77,22 @@ __device__ __forceinline__ float u01(uint32_t u) { return (float)u * 2.328306436
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float div_fast(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
+// cos(x) for a scattering angle x in [0, pi]: one quadrant reduction (q = 0, 1, 2; Cody-Waite pi/2)
+// and the classic single-precision kernels on |r| <= pi/4 (coefficients of the FreeBSD/msun
+// k_cosf / k_sinf minimax polynomials).  About 1 ulp, like the library cosf it replaces, at a
+// third of the instructions: the generic routine must handle any argument, this one need not.
+__device__ __forceinline__ float cos_0_pi(float x) {
+  const float q = rintf(x * 0.636619772f);
+  float r = __fmaf_rn(q, -1.57079637050628662109375f, x);  // exact (Sterbenz)
+  r = __fmaf_rn(q, 4.371138828673793e-8f, r);
+  const float z = r * r;
+  const float c = __fmaf_rn(z, __fmaf_rn(z, __fmaf_rn(z, __fmaf_rn(z, 2.43904487962774090654e-5f, -1.38867637746099294692e-3f),
+                                                      4.16666233237390631894e-2f), -0.499999997251031003120f), 1.0f);
+  const float s = __fmaf_rn(r * z, __fmaf_rn(z, __fmaf_rn(z, __fmaf_rn(z, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f),
+                                                          8.3333293858894631756e-3f), -0.166666666416265235595f), r);
+  return q == 0.0f ? c : (q == 1.0f ? -s : -c);
+}
+
 // element i (0..3) of a Philox block without dynamic register indexing
 __device__ __forceinline__ uint32_t pick4(const uint32_t (&r)[4], uint32_t i) {
   const uint32_t a = (i & 1u) ? r[1] : r[0], b = (i & 1u) ? r[3] : r[2];
@@ -85,6 +101,11 @@ __device__ __forceinline__ uint32_t pick4(const uint32_t (&r)[4], uint32_t i) {
 
 __device__ __forceinline__ unsigned long long to_fixed(double v) {
   return (unsigned long long)__double2ll_rn(v * kTallyScale);
+}
+// photon weights and deposits lie in [0, 1]: a float times 2^32 is exact, so the conversion needs
+// no double arithmetic (1.0 itself does not fit 32 bits and is handled apart)
+__device__ __forceinline__ unsigned long long weight_to_fixed(float v) {
+  return v >= 1.0f ? (1ull << 32) : (unsigned long long)__float2uint_rn(v * 4294967296.0f);
 }
 
 // findIndex(value, table) for cell edges: largest i with e[i] <= v, clamped to [0, n-1]
@@ -186,6 +207,8 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
   int nScat = 0, nLegs = 0;
   unsigned long long chunkNext = 0, chunkEnd = 0;  // global mode, wave-uniform
   unsigned int cLegs = 0, cCross = 0, cColl = 0, cAbs = 0, cTop = 0, cSurf = 0, cKill = 0, cSurv = 0;
+  // DEBUG, wave level (lane 0): loop iterations and how many lanes each kind of phase served
+  unsigned long long wWalkIters = 0, wWalkLanes = 0, wEventPhases = 0, wEventLanes = 0, wLaunchPhases = 0, wSurfPhases = 0;
 
   for (unsigned long long unit = blockIdx.x;; unit += gridDim.x) {
     if (PRIV) {  // workgroup-uniform
@@ -213,6 +236,12 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
       const bool doLaunch = __popcll(mDead) >= p.launchThreshold || nBusy < p.eventThreshold;
       const bool doSurface = __popcll(mSurf) >= p.surfaceThreshold || nBusy < p.eventThreshold;
       const unsigned long long want = doLaunch ? mDead : 0ull;
+      if (DEBUG) {
+        wEventPhases++;
+        wEventLanes += __popcll(__ballot(state == ST_COLLIDE || state == ST_TOP));
+        if (want) wLaunchPhases++;
+        if (doSurface && mSurf) wSurfPhases++;
+      }
       if (want != 0ull) {  // wave-uniform
         const int nWant = __popcll(want);
         const int rank = __popcll(want & laneBelow);
@@ -335,7 +364,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
       // ---- deferred events -------------------------------------------------------------
       if (state == ST_TOP) {
         // out the top, computeRT :573-617: tally and free the lane
-        const unsigned long long dep = to_fixed((double)w);
+        const unsigned long long dep = weight_to_fixed(w);
         if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + (ix + p.nx * iy)), dep);
         else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + (ix + p.nx * iy)), dep);
         if (DEBUG) {
@@ -374,7 +403,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         }
         const float ssa = ssaA[(long long)c * nvox + oc];
         if (ssa < 1.0f) {  // absorption :765-771
-          const unsigned long long dep = to_fixed((double)w * (1.0 - (double)ssa));
+          const unsigned long long dep = weight_to_fixed(w * (1.0f - ssa));
           if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + cell), dep);
           else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + 2 * ncol + cell), dep);
           w = w * ssa;
@@ -401,7 +430,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           } else {
             ang = t[n - 1];
           }
-          const float cs = cosf(ang);
+          const float cs = cos_0_pi(ang);
           // next_direct :1921-1948
           float AX = 1.0f - 2.0f * uY, AY = 1.0f - 2.0f * uZ;
           float D = AX * AX + AY * AY;
@@ -414,7 +443,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
               D = AX * AX + AY * AY;
             }
           }
-          float B = sqrtf(div_fast(1.0f - cs * cs, D));
+          float B = __builtin_amdgcn_sqrtf(div_fast(1.0f - cs * cs, D));
           AX = AX * B;
           AY = AY * B;
           B = dx * AX - dy * AY;
@@ -430,7 +459,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         py = py + (double)tcur * (double)dy;
         pz = p.zSurf;
         iz = 0;
-        const unsigned long long dep = to_fixed((double)w);
+        const unsigned long long dep = weight_to_fixed(w);
         if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + ncol + (ix + p.nx * iy)), dep);
         else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + ncol + (ix + p.nx * iy)), dep);
         nScat++;
@@ -463,7 +492,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         if (DEBUG) cLegs++;
         uint32_t r[4];
         philox4x32_10(event, 0u, idLo, idHi, p.seedLo, p.seedHi, r);
-        tau = -logf(fmaxf(FLT_MIN, u01(r[0])));  // :554
+        tau = -__logf(fmaxf(FLT_MIN, u01(r[0])));  // :554 (hardware log2 * ln 2; u >= 2^-32, no denormals)
         uX = u01(r[1]); uY = u01(r[2]); uZ = u01(r[3]);
         acc = 0.0f; tcur = 0.0f;
         // opticalProperties.f95:1690-1712: side 1 where direction >= 0; huge step for a zero cosine
@@ -483,6 +512,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
       // accumulateExtinctionAlongPath :1697-1814
       int nWalk;
       do {
+        if (DEBUG) { wWalkIters++; wWalkLanes += __popcll(__ballot(state == ST_WALK)); }
         if (state == ST_WALK) {
           float tmin = tnx;
           int ax = 0;
@@ -545,6 +575,11 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
     atomicAdd(p.counters + 5, (unsigned long long)cSurf);
     atomicAdd(p.counters + 6, (unsigned long long)cKill);
     atomicAdd(p.counters + 7, (unsigned long long)cSurv);
+    if (lane == 0) {
+      atomicAdd(p.counters + 8, wWalkIters); atomicAdd(p.counters + 9, wWalkLanes);
+      atomicAdd(p.counters + 10, wEventPhases); atomicAdd(p.counters + 11, wEventLanes);
+      atomicAdd(p.counters + 12, wLaunchPhases); atomicAdd(p.counters + 13, wSurfPhases);
+    }
   }
 }
 

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--bpc", type=int, nargs="*", default=[0])
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--ssa", type=float, default=0.99)
+    ap.add_argument("--counters", action="store_true")
     ap.add_argument("--inflight", type=int, nargs="*", default=[-1])
     ap.add_argument("--lthr", type=int, nargs="*", default=[0])
     ap.add_argument("--sthr", type=int, nargs="*", default=[0])
@@ -49,6 +50,11 @@ def main():
                 n = integ.computeRadiativeTransfer(dom, rng, photons, a.ppb, a.batches)
                 dt = time.time() - t
                 rates.append((n / dt, n / (integ.lastTraceMs() * 1e-3)))
+            if a.counters:
+                integ.enableCounters(True)
+                integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(99), photons, a.ppb, a.batches)
+                c = integ.counters(); integ.enableCounters(False)
+                print('   walk iters %.4g lanes/iter %.1f | event phases %.4g lanes/phase %.1f | launch phases %.4g surf phases %.4g | walk iters per event phase %.2f' % (c['walkIterations'], c['walkLanes']/max(1,c['walkIterations']), c['eventPhases'], c['eventLanes']/max(1,c['eventPhases']), c['launchPhases'], c['surfacePhases'], c['walkIterations']/max(1,c['eventPhases'])))
             res = integ.reportResults()
             print("case=%s bpc=%d priv=%d block=%d thr=%d lthr=%d sthr=%d brick=%d inflight=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
                 a.case, bpc, priv, block, thr, lthr, sthr, brick, inflight, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
