@@ -6,6 +6,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -752,7 +753,24 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
   p.slabs = scratch; p.slabStride = slabStride;
   p.ppb = (unsigned long long)n; p.total = (unsigned long long)n; p.firstPhoton = firstPhotonId;
   p.fates = dF; p.counters = c->dEventCounters;
+  double *dTrace = nullptr;
+  const int traceCap = 4096;
+  if (const char *tp = getenv("MCBRAT_TRACE_PHOTON")) {  // development aid: per-collision records of one photon
+    HIP_OK(c, hipMalloc((void **)&dTrace, sizeof(double) * 12 * traceCap));
+    HIP_OK(c, hipMemsetAsync(dTrace, 0, sizeof(double) * 12 * traceCap, c->stream));
+    p.traceBuf = dTrace; p.traceIndex = strtoull(tp, nullptr, 10); p.traceCap = traceCap;
+  }
   int rc = launch_trace(c, p, true, 1);
+  if (!rc && dTrace) {
+    std::vector<double> h(12 * traceCap);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h.data(), dTrace, sizeof(double) * h.size(), hipMemcpyDeviceToHost);
+    for (int i = 0; i < traceCap && h[12 * i] > 0; ++i)
+      fprintf(stderr, "GPUTRACE %d ev %.0f cell %.0f %.0f %.0f pos %.17g %.17g %.17g dir %.9g %.9g %.9g tau %.9g w %.9g\n", i, h[12 * i],
+              h[12 * i + 1], h[12 * i + 2], h[12 * i + 3], h[12 * i + 4], h[12 * i + 5], h[12 * i + 6], h[12 * i + 7], h[12 * i + 8],
+              h[12 * i + 9], h[12 * i + 10], h[12 * i + 11]);
+    (void)hipFree(dTrace);
+  }
   if (!rc) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(fates, dF, sizeof(mcbrat_fate) * (size_t)n, hipMemcpyDeviceToHost);

@@ -66,7 +66,10 @@ struct DevParams {
   int surfaceThreshold;           // lanes queued before surface reflections are served
   // debug / measurement
   mcbrat_fate *fates;             // non-null: record per-photon fate (index = photon index)
-  unsigned long long *counters;   // non-null: 8 event counters
+  unsigned long long *counters;   // non-null: event counters
+  double *traceBuf;               // DEBUG: per-collision records of one photon (12 doubles each)
+  unsigned long long traceIndex;  // photon index to trace
+  int traceCap;
 };
 
 }  // namespace mcbrat

@@ -74,8 +74,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 __device__ __forceinline__ float u01(uint32_t u) { return (float)u * 2.3283064365386963e-10f; }
 
 // 1/x and a/b with the hardware reciprocal (1 ulp): geometry set-up and direction algebra
+#ifdef MCBRAT_PRECISE_MATH  // A/B switch: correctly rounded division / library log, cos, sqrt everywhere
+__device__ __forceinline__ float rcp_fast(float x) { return 1.0f / x; }
+__device__ __forceinline__ float div_fast(float a, float b) { return a / b; }
+#else
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float div_fast(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#endif
 
 // cos(x) for a scattering angle x in [0, pi]: one quadrant reduction (q = 0, 1, 2; Cody-Waite pi/2)
 // and the classic single-precision kernels on |r| <= pi/4 (coefficients of the FreeBSD/msun
@@ -381,6 +386,11 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           py = py + s * (double)dy;
           pz = pz + s * (double)dz;
         }
+        if (DEBUG && p.traceBuf && ((((unsigned long long)idHi << 32) | idLo) - p.firstPhoton) == p.traceIndex && nScat < p.traceCap) {
+          double *t = p.traceBuf + 12 * nScat;  // one record per collision of the traced photon
+          t[0] = event; t[1] = ix + 1; t[2] = iy + 1; t[3] = iz + 1; t[4] = px; t[5] = py; t[6] = pz;
+          t[7] = dx; t[8] = dy; t[9] = dz; t[10] = tau; t[11] = w;
+        }
         nScat++;
         if (DEBUG) cColl++;
         const CellRef cr = locate_cell<BRICK>(p, ix, iy, iz);
@@ -425,12 +435,20 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           const int ai = (int)(uX * (float)n) + 1;
           float ang;
           if (ai < n) {
+            #ifdef MCBRAT_PRECISE_MATH
+            const float left = uX - (float)(ai - 1) / (float)n;
+#else
             const float left = uX - (float)(ai - 1) * p.tblInvN[c];
+#endif
             ang = (1.0f - left) * t[ai - 1] + left * t[ai];
           } else {
             ang = t[n - 1];
           }
+#ifdef MCBRAT_PRECISE_MATH
+          const float cs = cosf(ang);
+#else
           const float cs = cos_0_pi(ang);
+#endif
           // next_direct :1921-1948
           float AX = 1.0f - 2.0f * uY, AY = 1.0f - 2.0f * uZ;
           float D = AX * AX + AY * AY;
@@ -443,7 +461,11 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
               D = AX * AX + AY * AY;
             }
           }
+#ifdef MCBRAT_PRECISE_MATH
+          float B = sqrtf(div_fast(1.0f - cs * cs, D));
+#else
           float B = __builtin_amdgcn_sqrtf(div_fast(1.0f - cs * cs, D));
+#endif
           AX = AX * B;
           AY = AY * B;
           B = dx * AX - dy * AY;
@@ -492,7 +514,12 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         if (DEBUG) cLegs++;
         uint32_t r[4];
         philox4x32_10(event, 0u, idLo, idHi, p.seedLo, p.seedHi, r);
-        tau = -__logf(fmaxf(FLT_MIN, u01(r[0])));  // :554 (hardware log2 * ln 2; u >= 2^-32, no denormals)
+#ifdef MCBRAT_PRECISE_MATH
+        tau = -logf(fmaxf(FLT_MIN, u01(r[0])));
+#else
+        tau = -__logf(fmaxf(FLT_MIN, u01(r[0])));
+#endif
+         // :554 (hardware log2 * ln 2; u >= 2^-32, no denormals)
         uX = u01(r[1]); uY = u01(r[2]); uZ = u01(r[3]);
         acc = 0.0f; tcur = 0.0f;
         // opticalProperties.f95:1690-1712: side 1 where direction >= 0; huge step for a zero cosine

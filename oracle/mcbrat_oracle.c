@@ -12,6 +12,7 @@
 #include "mcbrat_oracle.h"
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -701,6 +702,8 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
   }
   uint64_t drawsAtStart = R->ndraws;
 
+  const char *traceEnv = getenv("ORC_TRACE_PHOTON");
+  const int64_t tracePhoton = traceEnv ? (int64_t)strtoll(traceEnv, NULL, 10) : -1;
   int64_t nPhotons = 0;
   for (int64_t ip = 0; ip < numPhotons; ip++) { /* photonLoop :463 */
     launch_t L;
@@ -777,6 +780,9 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
         if (photonWeight <= FLT_MIN) { cnt.surfaceAbsorbed++; fate = 1; fateWeight = wBefore; break; }
         make_direction_cosines(mu, phi, dir);
       } else { /* scattering event :703-821 */
+        if (tracePhoton >= 0 && ip == tracePhoton) /* development aid: ORC_TRACE_PHOTON=<index> */
+          fprintf(stderr, "ORCTRACE %d ev %u cell %d %d %d pos %.17g %.17g %.17g dir %.9g %.9g %.9g tau %.9g w %.9g\n", scatteringOrder,
+                  R->event, xIndex, yIndex, zIndex, xPos, yPos, zPos, dir[0], dir[1], dir[2], tauToTravel, photonWeight);
         scatteringOrder++;
         cnt.collisions++;
         if (P->totalExt[IDX3(P, xIndex, yIndex, zIndex)] <= 0.0) { /* :728-754 */

@@ -114,7 +114,13 @@ def oracle_problem(case, nsteps=10001, use_russian_roulette=True, lw_flag=-1.0):
     from oracle import oracle as O
     nx, ny, nz = len(case["xe"]) - 1, len(case["ye"]) - 1, len(case["ze"]) - 1
     tot, cum, ssa, pfi = O.optical_properties_by_component(nx, ny, nz, case["components"])
-    tables = [np.stack([O.inverse_table_legendre(c, nsteps) for c in comp["legendre"]]) for comp in case["components"]]
+    tables = []
+    for comp in case["components"]:
+        if "tabulated" in comp:
+            tables.append(np.stack([O.inverse_table_tabulated(a, O.normalize_phase_function(a, v), nsteps)
+                                    for a, v in comp["tabulated"]]))
+        else:
+            tables.append(np.stack([O.inverse_table_legendre(c, nsteps) for c in comp["legendre"]]))
     return O.Problem(case["xe"], case["ye"], case["ze"], tot, cum, ssa, pfi, case["albedo"], tables,
                      use_russian_roulette=use_russian_roulette, lw_flag=lw_flag)
 
@@ -125,7 +131,10 @@ def product_domain(case):
     dom = M.new_Domain(case["xe"], case["ye"], case["ze"], temps=case.get("temps"),
                        surfaceAlbedo=case["albedo"], lambda_um=case.get("lambda_um", 0.0))
     for i, comp in enumerate(case["components"]):
-        table = M.new_PhaseFunctionTable([M.new_PhaseFunction(c) for c in comp["legendre"]])
+        if "tabulated" in comp:
+            table = M.new_PhaseFunctionTable([M.new_PhaseFunction(a, v) for a, v in comp["tabulated"]])
+        else:
+            table = M.new_PhaseFunctionTable([M.new_PhaseFunction(c) for c in comp["legendre"]])
         dom.addOpticalComponent("component%d" % (i + 1), comp["ext"], comp["ssa"], comp["pfIndex"], table,
                                 zLevelBase=comp.get("zLevelBase", 1))
     dom.getOpticalPropertiesByComponent()
@@ -136,3 +145,32 @@ def radar_like(n=128, nz=64, seed=20240602):
     """Config 5: optically thick, strongly absorbing 3-D field: as landsat_like with a
     heavier tail (sigma 1.2, tau up to ~100+) and omega0 = 0.9, so that Russian roulette is played often."""
     return landsat_like(n=n, nz=nz, sigma=1.2, mean_tau=20.0, seed=seed, ssa_cloud=0.9, rayleigh=True)
+
+
+def tabulated_two_lobe(n_angles=361):
+    """An angle/value phase function (the storage Mie tables use, src/scatteringPhaseFunctions.f95:104-164):
+    forward HG lobe plus a weak backward lobe, tabulated on a uniform angle grid."""
+    ang = np.linspace(0.0, np.pi, n_angles).astype(np.float32)
+    ang[-1] = np.float32(np.pi)
+    mu = np.cos(ang.astype(np.float64))
+    hg = lambda g: (1 - g * g) / (1 + g * g - 2 * g * mu) ** 1.5  # noqa: E731
+    return ang, (0.9 * hg(0.8) + 0.1 * hg(-0.4)).astype(np.float32)
+
+
+def stretched_grid_cloud(nx=24, ny=10, nz=18, seed=3):
+    """Genuinely non-uniform x, y and z spacing (geometric stretching), lognormal extinction, two
+    angle/value phase-function entries + one Legendre entry in separate components."""
+    rng = np.random.default_rng(seed)
+    xe = np.concatenate([[0.0], np.cumsum(0.02 * 1.06 ** np.arange(nx))])
+    ye = np.concatenate([[0.0], np.cumsum(0.05 * 0.95 ** np.arange(ny))])
+    ze = np.concatenate([[0.0], np.cumsum(0.03 * 1.1 ** np.arange(nz))])
+    ext = np.exp(rng.normal(np.log(4.0), 0.9, (nx, ny, nz)))
+    ext[:, :, :2] = 0.0  # clear layers at the bottom
+    pfi = rng.integers(1, 3, (nx, ny, nz)).astype(np.int32)
+    ang, val = tabulated_two_lobe()
+    _, val2 = tabulated_two_lobe()
+    return dict(name="stretched", xe=xe, ye=ye, ze=ze, albedo=0.25,
+                components=[dict(ext=ext, ssa=np.where(ext > 0, 0.97, 0.0), pfIndex=pfi,
+                                 tabulated=[(ang, val), (ang, (val2 * (1 + 0.3 * np.cos(ang) ** 2)).astype(np.float32))]),
+                            dict(ext=0.05 * np.ones(nz), ssa=np.ones(nz), pfIndex=np.ones(nz, np.int32),
+                                 legendre=[np.array([0.0, 0.1], np.float32)])])
