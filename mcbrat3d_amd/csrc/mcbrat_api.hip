@@ -73,6 +73,7 @@ struct mcbrat_ctx {
   int maxBatchesInFlight = 0;  // 0: bounded by memory
   int privMode = 1;            // 1: LDS-private tallies when the slab fits, 0: always global atomics
   int blockSize = 0;           // 0: chosen by plan_launch
+  int gridLdsMode = 1;         // stage the optical grid in LDS when it fits (private-tally mode)
   bool countersOn = false;
   float lastTraceMs = 0.f;
   mcbrat_counters lastCounters{};
@@ -275,7 +276,7 @@ constexpr size_t kTableLdsLimit = 48 * 1024;   // tables above this stay in L2
 constexpr size_t kPrivSlabLimit = 32 * 1024;   // private tally slab above this -> global atomics
 
 struct LaunchPlan {
-  bool tblLds, priv, brick;
+  bool tblLds, priv, brick, gridLds;
   int block;
   size_t lds;
 };
@@ -290,7 +291,11 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
   const size_t bg = L.brick ? sizeof(float) * (size_t)((c->nz + 3) & ~3) : 0;
   L.tblLds = tbl <= kTableLdsLimit && edges + bg + tbl + (L.priv ? slab : 0) <= kLdsBudget;
   if (L.priv && edges + bg + slab + (L.tblLds ? tbl : 0) > kLdsBudget) L.priv = false;
-  L.lds = edges + bg + (L.priv ? slab : 0) + (L.tblLds ? tbl : 0);
+  // small domains: the optical grid itself (ext + per-component cum, ssa, phase index) goes to LDS when it fits
+  const size_t nvox = (size_t)c->nx * c->ny * c->nz;
+  const size_t grid = nvox * 4 + (size_t)c->nc * nvox * (4 + 4) + (((size_t)c->nc * nvox + 1) & ~(size_t)1) * 2;
+  L.gridLds = L.priv && c->gridLdsMode != 0 && edges + bg + slab + grid + (L.tblLds ? tbl : 0) <= kLdsBudget;
+  L.lds = edges + bg + (L.priv ? slab : 0) + (L.gridLds ? grid : 0) + (L.tblLds ? tbl : 0);
   L.block = c->blockSize > 0 ? c->blockSize : ((L.tblLds || L.priv) && L.lds > 16 * 1024 ? 512 : 256);
   return L;
 }
@@ -338,6 +343,7 @@ int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatche
 
 int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   LaunchPlan L = plan_launch(c, (size_t)p.slabStride);
+  p.gridInLds = L.gridLds ? 1 : 0;
   if (L.priv && L.brick) {  // fill_params chose the brick arrays: private tallies give way
     L.priv = false;
     L.lds = plan_launch_lds(c, L);
@@ -621,7 +627,7 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   if (eventThreshold > 0) { c->eventThreshold = eventThreshold; c->autoTune = false; }
   if (eventThreshold == 0) { c->autoTune = true; c->tuned = false; }
   if (maxBatchesInFlight >= 0) c->maxBatchesInFlight = maxBatchesInFlight;
-  if (privateTallies >= 0) c->privMode = privateTallies ? 1 : 0;
+  if (privateTallies >= 0) { c->privMode = privateTallies ? 1 : 0; c->gridLdsMode = privateTallies == 2 ? 0 : 1; }
   if (blockSize == 0 || blockSize == 256 || blockSize == 512) c->blockSize = blockSize;
   else if (blockSize > 0) return fail(c, "set_tuning: blockSize must be 0, 256 or 512");
   if (launchThreshold > 0) c->launchThreshold = launchThreshold;

@@ -169,7 +169,8 @@ template <int BLOCK, bool TBL_LDS, bool PRIV, bool BRICK, bool DEBUG>
 __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel(const DevParams p) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   // LDS map: [edges x|y|z (double)] [private tally slab (i64), PRIV] [unit cursor, PRIV]
-  //          [background extinction per layer, BRICK] [tables (float), TBL_LDS]
+  //          [background extinction per layer, BRICK] [optical grid, PRIV && gridInLds]
+  //          [tables (float), TBL_LDS]
   double *s_edge = reinterpret_cast<double *>(smem_raw);
   const int nEdges = p.nx + p.ny + p.nz + 3;
   const int ncol = p.nx * p.ny;
@@ -177,7 +178,14 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
   long long *s_slab = reinterpret_cast<long long *>(s_edge + nEdges);
   unsigned *s_cursor = reinterpret_cast<unsigned *>(s_slab + slabLen);
   float *s_bgExt = reinterpret_cast<float *>(s_cursor + (PRIV ? 4 : 0));  // BRICK: background extinction per layer
-  float *s_tbl = s_bgExt + (BRICK ? ((p.nz + 3) & ~3) : 0);
+  // PRIV (small domains): the whole optical grid is staged in LDS too -- extinction, ssa, phase index
+  const bool gridLds = PRIV && p.gridInLds;
+  const int nvoxS = gridLds ? ncol * p.nz : 0;
+  float *s_ext = s_bgExt + (BRICK ? ((p.nz + 3) & ~3) : 0);
+  float *s_ssa = s_ext + nvoxS;                       // [nc][nvox]
+  float *s_cum = s_ssa + (size_t)p.nc * nvoxS;        // [nc][nvox]
+  uint16_t *s_pfi = reinterpret_cast<uint16_t *>(s_cum + (size_t)p.nc * nvoxS);  // [nc][nvox]
+  float *s_tbl = reinterpret_cast<float *>(s_pfi + (((size_t)p.nc * nvoxS + 1) & ~(size_t)1));
   for (int i = threadIdx.x; i < nEdges; i += BLOCK) s_edge[i] = p.edges[i];
   if (TBL_LDS)
     for (int i = threadIdx.x; i < p.tblTotalFloats; i += BLOCK) s_tbl[i] = p.tables[i];
@@ -187,6 +195,10 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
   }
   if (BRICK)
     for (int i = threadIdx.x; i < p.nz; i += BLOCK) s_bgExt[i] = p.bgExt[i];
+  if (gridLds) {  // coalesced HBM reads, once per workgroup
+    for (int i = threadIdx.x; i < nvoxS; i += BLOCK) s_ext[i] = p.ext[i];
+    for (int i = threadIdx.x; i < p.nc * nvoxS; i += BLOCK) { s_ssa[i] = p.ssa[i]; s_cum[i] = p.cum[i]; s_pfi[i] = p.pfi[i]; }
+  }
   __syncthreads();
   const float *__restrict__ tbl = TBL_LDS ? s_tbl : p.tables;
   const int offY = p.nx + 1, offZ = p.nx + p.ny + 2;  // edge table offsets
@@ -354,7 +366,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
               iz = min((int)fl, p.nz - 1);
               pz = s_edge[offZ + iz] + (t - fl) * (s_edge[offZ + iz + 1] - s_edge[offZ + iz]);
             }
-            extCur = load_ext<BRICK>(p, s_bgExt, locate_cell<BRICK>(p, ix, iy, iz), iz);
+            extCur = gridLds ? s_ext[ix + p.nx * (iy + p.ny * iz)] : load_ext<BRICK>(p, s_bgExt, locate_cell<BRICK>(p, ix, iy, iz), iz);
             if (p.lwFlag && pz > 0.0) {  // :504-508 emission counts as negative absorption
               const int cell = ix + p.nx * (iy + p.ny * iz);
               if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + cell), to_fixed(-1.0));
@@ -398,9 +410,9 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         // optics of this cell: dense grid, stored brick, or the layer's background record
         const long long nvox = BRICK ? (cr.stored >= 0 ? p.nStored : (long long)p.nz) : (long long)ncol * p.nz;
         const int oc = BRICK ? (cr.stored >= 0 ? cr.stored : iz) : cell;
-        const float *cumA = (BRICK && cr.stored < 0) ? p.bgCum : p.cum;
-        const float *ssaA = (BRICK && cr.stored < 0) ? p.bgSsa : p.ssa;
-        const uint16_t *pfiA = (BRICK && cr.stored < 0) ? p.bgPfi : p.pfi;
+        const float *cumA = gridLds ? s_cum : ((BRICK && cr.stored < 0) ? p.bgCum : p.cum);
+        const float *ssaA = gridLds ? s_ssa : ((BRICK && cr.stored < 0) ? p.bgSsa : p.ssa);
+        const uint16_t *pfiA = gridLds ? s_pfi : ((BRICK && cr.stored < 0) ? p.bgPfi : p.pfi);
         uint32_t r1[4] = {0u, 0u, 0u, 0u};
         bool haveR1 = false;
         int c = 0;  // component pick :759-760 (findIndex over [0, cumExt(:)])
@@ -571,7 +583,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
               const float tNew = (float)(edge - origin) * (ax == 0 ? ivx : (ax == 1 ? ivy : ivz));
               tnx = ax == 0 ? tNew : tnx; tny = ax == 1 ? tNew : tny; tnz = ax == 2 ? tNew : tnz;
               ix = ax == 0 ? iAx : ix; iy = ax == 1 ? iAx : iy; iz = ax == 2 ? iAx : iz;
-              extCur = load_ext<BRICK>(p, s_bgExt, locate_cell<BRICK>(p, ix, iy, iz), iz);
+              extCur = gridLds ? s_ext[ix + p.nx * (iy + p.ny * iz)] : load_ext<BRICK>(p, s_bgExt, locate_cell<BRICK>(p, ix, iy, iz), iz);
             }
           }
         }
