@@ -438,6 +438,7 @@ int mcbrat_set_grid(mcbrat_ctx *c, int32_t nx, int32_t ny, int32_t nz, const dou
   for (int i = 0; i < nx; ++i) if (!(xe[i + 1] > xe[i])) return fail(c, "new_Domain: x edges must be increasing, unique.");
   for (int i = 0; i < ny; ++i) if (!(ye[i + 1] > ye[i])) return fail(c, "new_Domain: y edges must be increasing, unique.");
   for (int i = 0; i < nz; ++i) if (!(ze[i + 1] > ze[i])) return fail(c, "new_Domain: z edges must be increasing, unique.");
+  if ((long long)nx * ny * nz > 0x7fffffffLL / 2) return fail(c, "new_Integrator: more than 2^30 cells are not supported.");
   (void)hipSetDevice(c->device);
   c->nx = nx; c->ny = ny; c->nz = nz;
   c->xe.assign(xe, xe + nx + 1); c->ye.assign(ye, ye + ny + 1); c->ze.assign(ze, ze + nz + 1);
