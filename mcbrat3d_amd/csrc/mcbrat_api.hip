@@ -305,7 +305,7 @@ size_t plan_launch_lds(const mcbrat_ctx *c, const LaunchPlan &L) {
          (L.tblLds ? sizeof(float) * (size_t)c->tblTotalFloats : 0);
 }
 
-template <int BLOCK, bool TBL, bool PRIV, bool BRICK, bool DBG>
+template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG>
 int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   int perCU = c->blocksPerCU;
   if (perCU <= 0) {
@@ -333,19 +333,21 @@ int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
 template <int BLOCK, bool DBG>
 int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatches) {
   // instantiated combinations: private tallies (small domains) and bricks (large ones) never coincide
-  if (L.priv) return L.tblLds ? launch_trace_t<BLOCK, true, true, false, DBG>(c, p, L.lds, nBatches)
-                              : launch_trace_t<BLOCK, false, true, false, DBG>(c, p, L.lds, nBatches);
-  if (L.brick) return L.tblLds ? launch_trace_t<BLOCK, true, false, true, DBG>(c, p, L.lds, nBatches)
-                               : launch_trace_t<BLOCK, false, false, true, DBG>(c, p, L.lds, nBatches);
-  return L.tblLds ? launch_trace_t<BLOCK, true, false, false, DBG>(c, p, L.lds, nBatches)
-                  : launch_trace_t<BLOCK, false, false, false, DBG>(c, p, L.lds, nBatches);
+  if (L.priv && L.gridLds) return L.tblLds ? launch_trace_t<BLOCK, true, 2, false, DBG>(c, p, L.lds, nBatches)
+                                           : launch_trace_t<BLOCK, false, 2, false, DBG>(c, p, L.lds, nBatches);
+  if (L.priv) return L.tblLds ? launch_trace_t<BLOCK, true, 1, false, DBG>(c, p, L.lds, nBatches)
+                              : launch_trace_t<BLOCK, false, 1, false, DBG>(c, p, L.lds, nBatches);
+  if (L.brick) return L.tblLds ? launch_trace_t<BLOCK, true, 0, true, DBG>(c, p, L.lds, nBatches)
+                               : launch_trace_t<BLOCK, false, 0, true, DBG>(c, p, L.lds, nBatches);
+  return L.tblLds ? launch_trace_t<BLOCK, true, 0, false, DBG>(c, p, L.lds, nBatches)
+                  : launch_trace_t<BLOCK, false, 0, false, DBG>(c, p, L.lds, nBatches);
 }
 
 int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   LaunchPlan L = plan_launch(c, (size_t)p.slabStride);
-  p.gridInLds = L.gridLds ? 1 : 0;
   if (L.priv && L.brick) {  // fill_params chose the brick arrays: private tallies give way
     L.priv = false;
+    L.gridLds = false;
     L.lds = plan_launch_lds(c, L);
   }
   if (L.block == 512) return debug ? launch_trace_b<512, true>(c, p, L, nBatches) : launch_trace_b<512, false>(c, p, L, nBatches);

@@ -28,7 +28,6 @@ struct DevParams {
   const float *ssa;               // [nc][nvox]
   const uint16_t *pfi;            // [nc][nvox] 0-based entry
   float albedo;
-  int gridInLds;                  // PRIV mode: stage ext/cum/ssa/pfi in LDS as well
   // brick layout of the optics (large, mostly-background domains): ext/cum/ssa/pfi then hold the
   // STORED bricks only (64 cells each, [component][nStored]); background cells use bg* [component][nz]
   const uint32_t *brickTable;     // [nbz][nby][nbx] offset of the brick's 64 cells, 0xffffffff = background

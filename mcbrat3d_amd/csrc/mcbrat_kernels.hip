@@ -165,11 +165,12 @@ __device__ __forceinline__ float load_ext(const DevParams &p, const float *s_bgE
   return r.stored >= 0 ? p.ext[r.stored] : s_bgExt[iz];
 }
 
-template <int BLOCK, bool TBL_LDS, bool PRIV, bool BRICK, bool DEBUG>
+// PRIV: 0 tallies by global atomics, 1 LDS-private tally slab, 2 private slab and the optical grid in LDS too
+template <int BLOCK, bool TBL_LDS, int PRIV, bool BRICK, bool DEBUG>
 __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel(const DevParams p) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   // LDS map: [edges x|y|z (double)] [private tally slab (i64), PRIV] [unit cursor, PRIV]
-  //          [background extinction per layer, BRICK] [optical grid, PRIV && gridInLds]
+  //          [background extinction per layer, BRICK] [optical grid, PRIV == 2]
   //          [tables (float), TBL_LDS]
   double *s_edge = reinterpret_cast<double *>(smem_raw);
   const int nEdges = p.nx + p.ny + p.nz + 3;
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
   unsigned *s_cursor = reinterpret_cast<unsigned *>(s_slab + slabLen);
   float *s_bgExt = reinterpret_cast<float *>(s_cursor + (PRIV ? 4 : 0));  // BRICK: background extinction per layer
   // PRIV (small domains): the whole optical grid is staged in LDS too -- extinction, ssa, phase index
-  const bool gridLds = PRIV && p.gridInLds;
+  constexpr bool gridLds = PRIV == 2;
   const int nvoxS = gridLds ? ncol * p.nz : 0;
   float *s_ext = s_bgExt + (BRICK ? ((p.nz + 3) & ~3) : 0);
   float *s_ssa = s_ext + nvoxS;                       // [nc][nvox]
@@ -220,7 +221,8 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
   float ivx = 0, ivy = 0, ivz = 0;    // 1/direction
   float tnx = 0, tny = 0, tnz = 0, tcur = 0;  // distance along the leg to the next x/y/z face
   float acc = 0, tau = 0, w = 0, extCur = 0, uX = 0, uY = 0, uZ = 0;
-  int ix = 0, iy = 0, iz = 0;
+  int ex = 0, ey = 0, ez = 0;  // index in the LDS edge table of the next x / y / z face of the leg
+  int cell = 0;                // linear index of the current cell
   int nScat = 0, nLegs = 0;
   unsigned long long chunkNext = 0, chunkEnd = 0;  // global mode, wave-uniform
   unsigned int cLegs = 0, cCross = 0, cColl = 0, cAbs = 0, cTop = 0, cSurf = 0, cKill = 0, cSurv = 0;
@@ -243,6 +245,8 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
     for (;;) {
       // ================= event phase: every lane that is not walking =====================
       bool needLeg = false;
+      // 0-based cell of a waiting lane: the face ahead minus one where the leg runs forward
+      int ix = ex - (dx >= 0.0f ? 1 : 0), iy = ey - offY - (dy >= 0.0f ? 1 : 0), iz = ez - offZ - (dz >= 0.0f ? 1 : 0);
       // Launches and surface reflections are rare next to collisions (1 and ~0.7 per ~17 legs in
       // the I3RC step cloud).  Serving them whenever a single lane asks would run their code at a
       // few percent lane occupancy in almost every event phase, so they wait until enough lanes
@@ -366,9 +370,9 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
               iz = min((int)fl, p.nz - 1);
               pz = s_edge[offZ + iz] + (t - fl) * (s_edge[offZ + iz + 1] - s_edge[offZ + iz]);
             }
-            extCur = gridLds ? s_ext[ix + p.nx * (iy + p.ny * iz)] : load_ext<BRICK>(p, s_bgExt, locate_cell<BRICK>(p, ix, iy, iz), iz);
+            cell = ix + p.nx * (iy + p.ny * iz);
+            extCur = gridLds ? s_ext[cell] : load_ext<BRICK>(p, s_bgExt, locate_cell<BRICK>(p, ix, iy, iz), iz);
             if (p.lwFlag && pz > 0.0) {  // :504-508 emission counts as negative absorption
-              const int cell = ix + p.nx * (iy + p.ny * iz);
               if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + cell), to_fixed(-1.0));
               else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + 2 * ncol + cell), to_fixed(-1.0));
             }
@@ -405,8 +409,10 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         }
         nScat++;
         if (DEBUG) cColl++;
-        const CellRef cr = locate_cell<BRICK>(p, ix, iy, iz);
-        const int cell = cr.dense;
+        CellRef cr;
+        cr.dense = cell;
+        cr.stored = -1;
+        if (BRICK) cr = locate_cell<BRICK>(p, ix, iy, iz);
         // optics of this cell: dense grid, stored brick, or the layer's background record
         const long long nvox = BRICK ? (cr.stored >= 0 ? p.nStored : (long long)p.nz) : (long long)ncol * p.nz;
         const int oc = BRICK ? (cr.stored >= 0 ? cr.stored : iz) : cell;
@@ -493,6 +499,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         py = py + (double)tcur * (double)dy;
         pz = p.zSurf;
         iz = 0;
+        cell = ix + p.nx * iy;
         const unsigned long long dep = weight_to_fixed(w);
         if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + ncol + (ix + p.nx * iy)), dep);
         else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + ncol + (ix + p.nx * iy)), dep);
@@ -535,11 +542,14 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         uX = u01(r[1]); uY = u01(r[2]); uZ = u01(r[3]);
         acc = 0.0f; tcur = 0.0f;
         // opticalProperties.f95:1690-1712: side 1 where direction >= 0; huge step for a zero cosine
-        if (fabsf(dx) >= 2.0f * FLT_MIN) { ivx = rcp_fast(dx); tnx = (float)(s_edge[ix + (dx >= 0.0f ? 1 : 0)] - px) * ivx; }
+        ex = ix + (dx >= 0.0f ? 1 : 0);
+        ey = offY + iy + (dy >= 0.0f ? 1 : 0);
+        ez = offZ + iz + (dz >= 0.0f ? 1 : 0);
+        if (fabsf(dx) >= 2.0f * FLT_MIN) { ivx = rcp_fast(dx); tnx = (float)(s_edge[ex] - px) * ivx; }
         else { ivx = 0.0f; tnx = FLT_MAX; }
-        if (fabsf(dy) >= 2.0f * FLT_MIN) { ivy = rcp_fast(dy); tny = (float)(s_edge[offY + iy + (dy >= 0.0f ? 1 : 0)] - py) * ivy; }
+        if (fabsf(dy) >= 2.0f * FLT_MIN) { ivy = rcp_fast(dy); tny = (float)(s_edge[ey] - py) * ivy; }
         else { ivy = 0.0f; tny = FLT_MAX; }
-        if (fabsf(dz) >= 2.0f * FLT_MIN) { ivz = rcp_fast(dz); tnz = (float)(s_edge[offZ + iz + (dz >= 0.0f ? 1 : 0)] - pz) * ivz; }
+        if (fabsf(dz) >= 2.0f * FLT_MIN) { ivz = rcp_fast(dz); tnz = (float)(s_edge[ez] - pz) * ivz; }
         else { ivz = 0.0f; tnz = FLT_MAX; }
         state = ST_WALK;
       }
@@ -547,16 +557,19 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
       // (A lane that died in THIS phase still has `more` set: it gets its refill attempt next time.)
       if (__ballot(state != ST_DEAD || more) == 0ull) break;
 
-      // ================= walk phase: one voxel face per iteration, branch-free ================
-      // accumulateExtinctionAlongPath :1697-1814
+      // ================= walk phase: one voxel face per iteration ===========================
+      // accumulateExtinctionAlongPath :1697-1814.  Per axis the lane holds the index of the NEXT face
+      // in the LDS edge table (ex, ey, ez) and the distance to it; `cell` is the linear cell index.
+      // The crossed axis is served by its own short predicated block (add, bounds test, one LDS read),
+      // so no three-way selects over the axes are needed.
       int nWalk;
       do {
         if (DEBUG) { wWalkIters++; wWalkLanes += __popcll(__ballot(state == ST_WALK)); }
         if (state == ST_WALK) {
-          float tmin = tnx;
-          int ax = 0;
-          if (tny < tmin) { tmin = tny; ax = 1; }
-          if (tnz < tmin) { tmin = tnz; ax = 2; }
+          const bool yLtX = tny < tnx;
+          const float m2 = yLtX ? tny : tnx;
+          const bool isZ = tnz < m2;
+          const float tmin = isZ ? tnz : m2;
           const float accNew = acc + (tmin - tcur) * extCur;  // :1743
           if (accNew > tau) {
             state = ST_COLLIDE;  // :1729-1738: the stop point inside this cell is resolved in the event phase
@@ -564,27 +577,39 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
             acc = accNew;
             tcur = tmin;
             if (DEBUG) cCross++;
-            const float dAx = ax == 0 ? dx : (ax == 1 ? dy : dz);
-            const int fwd = dAx >= 0.0f ? 1 : 0;
-            int iAx = (ax == 0 ? ix : (ax == 1 ? iy : iz)) + (fwd ? 1 : -1);
-            const int nAx = ax == 0 ? p.nx : (ax == 1 ? p.ny : p.nz);
-            if (ax == 2 && (iAx >= nAx || iAx < 0)) {
-              state = iAx < 0 ? ST_SURFACE : ST_TOP;  // :1801-1812; tallied in the event phase
+            // integer state of the crossed axis (short predicated blocks) ...
+            if (isZ) {
+              ez += dz >= 0.0f ? 1 : -1;
+              if (ez > offZ + p.nz) state = ST_TOP;        // :1801-1812; tallied in the event phase
+              else if (ez < offZ) state = ST_SURFACE;
+              else cell += dz >= 0.0f ? ncol : -ncol;
+            } else if (yLtX) {
+              ey += dy >= 0.0f ? 1 : -1;
+              cell += dy >= 0.0f ? p.nx : -p.nx;
+              if (ey > offY + p.ny) { ey = offY + 1; cell -= ncol; py -= p.Ly; }          // periodic y :1782-1796:
+              else if (ey < offY) { ey = offY + p.ny - 1; cell += ncol; py += p.Ly; }     // continue in the next image
             } else {
-              if (iAx >= nAx) {  // periodic x / y :1782-1796: continue in the next image of the domain
-                iAx = 0;
-                if (ax == 0) px -= p.Lx; else py -= p.Ly;
-              } else if (iAx < 0) {
-                iAx = nAx - 1;
-                if (ax == 0) px += p.Lx; else py += p.Ly;
-              }
-              const double edge = s_edge[(ax == 0 ? 0 : (ax == 1 ? offY : offZ)) + iAx + fwd];
-              const double origin = ax == 0 ? px : (ax == 1 ? py : pz);
-              const float tNew = (float)(edge - origin) * (ax == 0 ? ivx : (ax == 1 ? ivy : ivz));
-              tnx = ax == 0 ? tNew : tnx; tny = ax == 1 ? tNew : tny; tnz = ax == 2 ? tNew : tnz;
-              ix = ax == 0 ? iAx : ix; iy = ax == 1 ? iAx : iy; iz = ax == 2 ? iAx : iz;
-              extCur = gridLds ? s_ext[ix + p.nx * (iy + p.ny * iz)] : load_ext<BRICK>(p, s_bgExt, locate_cell<BRICK>(p, ix, iy, iz), iz);
+              ex += dx >= 0.0f ? 1 : -1;
+              cell += dx >= 0.0f ? 1 : -1;
+              if (ex > p.nx) { ex = 1; cell -= p.nx; px -= p.Lx; }
+              else if (ex < 0) { ex = p.nx - 1; cell += p.nx; px += p.Lx; }
             }
+            // ... then ONE extinction read and ONE edge read for whichever axis it was (a lane that just
+            // left through the top or the surface reads a valid, unused entry)
+            if (gridLds) extCur = s_ext[cell];
+            else if (!BRICK) extCur = p.ext[cell];
+            else {
+              const int bz = min(max(ez - offZ - (dz >= 0.0f ? 1 : 0), 0), p.nz - 1);
+              extCur = load_ext<BRICK>(p, s_bgExt, locate_cell<BRICK>(p, ex - (dx >= 0.0f ? 1 : 0), ey - offY - (dy >= 0.0f ? 1 : 0), bz), bz);
+            }
+            const int eSel = isZ ? min(max(ez, offZ), offZ + p.nz) : (yLtX ? ey : ex);
+            const double edge = s_edge[eSel];
+            const double origin = isZ ? pz : (yLtX ? py : px);
+            const float iv = isZ ? ivz : (yLtX ? ivy : ivx);
+            const float tNew = (float)(edge - origin) * iv;
+            tnz = isZ ? tNew : tnz;
+            tny = (!isZ && yLtX) ? tNew : tny;
+            tnx = (!isZ && !yLtX) ? tNew : tnx;
           }
         }
         nWalk = __popcll(__ballot(state == ST_WALK));
