@@ -410,7 +410,7 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipMalloc((void **)&c->dCounter, sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc((void **)&c->dEventCounters, 16 * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc((void **)&c->dEventCounters, 32 * sizeof(unsigned long long)) != hipSuccess) {
     delete c;
     return nullptr;
   }
@@ -675,7 +675,7 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   p.ppb = (unsigned long long)ppb;
   p.fates = nullptr;
   p.counters = c->countersOn ? c->dEventCounters : nullptr;
-  if (c->countersOn) HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 16 * sizeof(unsigned long long), c->stream));
+  if (c->countersOn) HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 32 * sizeof(unsigned long long), c->stream));
 
   if (c->autoTune && !c->tuned) {
     if (autotune(c, p, (unsigned long long)ppb, (int)inFlight)) return 1;
@@ -712,6 +712,17 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   if (c->countersOn) {
     unsigned long long h[16];
     HIP_OK(c, hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost));
+#ifdef MCBRAT_STAMPS  // development aid: wave cycles per section of the tracing loop
+    {
+      unsigned long long st[16];
+      HIP_OK(c, hipMemcpy(st, c->dEventCounters + 16, sizeof(st), hipMemcpyDeviceToHost));
+      const char *names[9] = {"launch", "top", "collideA(pos,optics,absorb,roulette)", "collideB(angle,cos)", "collideC(next_direct)",
+                              "surface", "leg", "walk", "phase-head"};
+      double tot = 0;
+      for (int i = 0; i < 9; i++) tot += (double)st[i];
+      for (int i = 0; i < 9; i++) fprintf(stderr, "stamp %-40s %14llu  %5.1f %%\n", names[i], st[i], 100.0 * (double)st[i] / tot);
+    }
+#endif
     c->lastCounters = mcbrat_counters{(int64_t)h[0], (int64_t)h[1], (int64_t)h[2], (int64_t)h[3],
                                       (int64_t)h[4], (int64_t)h[5], (int64_t)h[6], (int64_t)h[7],
                                       (int64_t)h[8], (int64_t)h[9], (int64_t)h[10], (int64_t)h[11], (int64_t)h[12], (int64_t)h[13]};
@@ -755,7 +766,7 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
   HIP_OK(c, hipMemsetAsync(scratch, 0, sizeof(long long) * slabStride, c->stream));
   HIP_OK(c, hipMemsetAsync(dF, 0xff, sizeof(mcbrat_fate) * (size_t)n, c->stream));
   HIP_OK(c, hipMemsetAsync(c->dCounter, 0, sizeof(unsigned long long), c->stream));
-  HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 16 * sizeof(unsigned long long), c->stream));
+  HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 32 * sizeof(unsigned long long), c->stream));
   DevParams p;
   fill_params(c, p);
   p.seedLo = (uint32_t)seed; p.seedHi = (uint32_t)(seed >> 32);

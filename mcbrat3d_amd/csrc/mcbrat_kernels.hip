@@ -41,6 +41,15 @@
 
 #include "mcbrat_device.h"
 
+// Development aid: -DMCBRAT_STAMPS makes the DEBUG instantiation report wave cycles per section of the
+// loop in place of the event counters 0..7 (launch, top, collide A/B/C, surface, leg set-up, walk).
+#ifdef MCBRAT_STAMPS
+#define STAMP(i) do { if (DEBUG && p.counters) { const unsigned long long t_ = clock64(); \
+    if (lane == __ffsll((long long)__ballot(1)) - 1) { s_stamp[threadIdx.x >> 6][i] += t_ - s_tprev[threadIdx.x >> 6]; s_tprev[threadIdx.x >> 6] = t_; } } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace mcbrat {
 
 constexpr unsigned kChunk = 256;  // photon ids a wave takes per global atomic (global mode)
@@ -187,6 +196,15 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
   float *s_cum = s_ssa + (size_t)p.nc * nvoxS;        // [nc][nvox]
   uint16_t *s_pfi = reinterpret_cast<uint16_t *>(s_cum + (size_t)p.nc * nvoxS);  // [nc][nvox]
   float *s_tbl = reinterpret_cast<float *>(s_pfi + (((size_t)p.nc * nvoxS + 1) & ~(size_t)1));
+  // per-component table descriptors: indexed by a per-lane component number, so they must not stay in the
+  // kernel-argument segment (a vector load from there costs a trip to memory on every collision)
+  __shared__ int s_tblOffset[MCBRAT_MAX_COMPONENTS], s_tblNSteps[MCBRAT_MAX_COMPONENTS];
+  __shared__ float s_tblInvN[MCBRAT_MAX_COMPONENTS];
+  if (threadIdx.x < MCBRAT_MAX_COMPONENTS) {
+    s_tblOffset[threadIdx.x] = p.tblOffset[threadIdx.x];
+    s_tblNSteps[threadIdx.x] = p.tblNSteps[threadIdx.x];
+    s_tblInvN[threadIdx.x] = p.tblInvN[threadIdx.x];
+  }
   for (int i = threadIdx.x; i < nEdges; i += BLOCK) s_edge[i] = p.edges[i];
   if (TBL_LDS)
     for (int i = threadIdx.x; i < p.tblTotalFloats; i += BLOCK) s_tbl[i] = p.tables[i];
@@ -227,6 +245,10 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
   unsigned long long chunkNext = 0, chunkEnd = 0;  // global mode, wave-uniform
   unsigned int cLegs = 0, cCross = 0, cColl = 0, cAbs = 0, cTop = 0, cSurf = 0, cKill = 0, cSurv = 0;
   // DEBUG, wave level (lane 0): loop iterations and how many lanes each kind of phase served
+#ifdef MCBRAT_STAMPS
+  __shared__ unsigned long long s_tprev[BLOCK / 64], s_stamp[BLOCK / 64][9];
+  if (lane == 0) { s_tprev[threadIdx.x >> 6] = clock64(); for (int i = 0; i < 9; i++) s_stamp[threadIdx.x >> 6][i] = 0; }
+#endif
   unsigned long long wWalkIters = 0, wWalkLanes = 0, wEventPhases = 0, wEventLanes = 0, wLaunchPhases = 0, wSurfPhases = 0;
 
   for (unsigned long long unit = blockIdx.x;; unit += gridDim.x) {
@@ -263,6 +285,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         if (want) wLaunchPhases++;
         if (doSurface && mSurf) wSurfPhases++;
       }
+      STAMP(8);
       if (want != 0ull) {  // wave-uniform
         const int nWant = __popcll(want);
         const int rank = __popcll(want & laneBelow);
@@ -382,6 +405,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           }
         }
       }
+      STAMP(0);
       // ---- deferred events -------------------------------------------------------------
       if (state == ST_TOP) {
         // out the top, computeRT :573-617: tally and free the lane
@@ -393,7 +417,9 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           if (p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{0, ix + 1, iy + 1, p.nz + 1, nScat, nLegs, w};
         }
         state = ST_DEAD;
-      } else if (state == ST_COLLIDE) {
+      }
+      STAMP(1);
+      if (state == ST_COLLIDE) {
         // scattering event, computeRT :703-821 (the zero-extinction back-step :728-754 cannot
         // arise: a collision is only declared inside a cell with extinction > 0)
         {  // opticalProperties.f95:1729-1738: the point inside the cell where tau is used up
@@ -442,21 +468,22 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           if (u01(r1[1]) >= w) { w = 0.0f; if (DEBUG) cKill++; }
           else { w = 1.0f; if (DEBUG) cSurv++; }
         }
+        STAMP(2);
         if (w <= FLT_MIN) {  // :812
           if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{2, ix + 1, iy + 1, iz + 1, nScat, nLegs, 0.0f};
           state = ST_DEAD;
         } else {
           // computeScatteringAngle :1594-1621 (table point count N, floor-type lookup as written)
           const int pf = pfiA[(long long)c * nvox + oc];
-          const int n = p.tblNSteps[c];
-          const float *t = tbl + p.tblOffset[c] + (long long)pf * n;
+          const int n = s_tblNSteps[c];
+          const float *t = tbl + s_tblOffset[c] + (long long)pf * n;
           const int ai = (int)(uX * (float)n) + 1;
           float ang;
           if (ai < n) {
             #ifdef MCBRAT_PRECISE_MATH
             const float left = uX - (float)(ai - 1) / (float)n;
 #else
-            const float left = uX - (float)(ai - 1) * p.tblInvN[c];
+            const float left = uX - (float)(ai - 1) * s_tblInvN[c];
 #endif
             ang = (1.0f - left) * t[ai - 1] + left * t[ai];
           } else {
@@ -467,6 +494,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
 #else
           const float cs = cos_0_pi(ang);
 #endif
+          STAMP(3);
           // next_direct :1921-1948
           float AX = 1.0f - 2.0f * uY, AY = 1.0f - 2.0f * uZ;
           float D = AX * AX + AY * AY;
@@ -492,8 +520,11 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           dy = dy * D - AY;
           dz = dz * cs - copysignf(fabsf(B), dz * B);
           needLeg = true;
+          STAMP(4);
         }
-      } else if (state == ST_SURFACE && doSurface) {
+      }
+      STAMP(4);
+      if (state == ST_SURFACE && doSurface) {
         // surface, computeRT :619-676 (Lambertian); fluxDown gets the incident weight :634
         px = px + (double)tcur * (double)dx;  // where the leg met z0 (:1809-1812)
         py = py + (double)tcur * (double)dy;
@@ -526,6 +557,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           needLeg = true;
         }
       }
+      STAMP(5);
       // ---- start the next leg: tau and the per-axis face distances -------------------------
       if (needLeg) {
         event++;
@@ -536,7 +568,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
 #ifdef MCBRAT_PRECISE_MATH
         tau = -logf(fmaxf(FLT_MIN, u01(r[0])));
 #else
-        tau = -__logf(fmaxf(FLT_MIN, u01(r[0])));
+        tau = -0.693147182f * __builtin_amdgcn_logf(fmaxf(FLT_MIN, u01(r[0])));
 #endif
          // :554 (hardware log2 * ln 2; u >= 2^-32, no denormals)
         uX = u01(r[1]); uY = u01(r[2]); uZ = u01(r[3]);
@@ -555,6 +587,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
       }
       // wave-uniform exit: nothing alive and every lane has already been refused a new photon.
       // (A lane that died in THIS phase still has `more` set: it gets its refill attempt next time.)
+      STAMP(6);
       if (__ballot(state != ST_DEAD || more) == 0ull) break;
 
       // ================= walk phase: one voxel face per iteration ===========================
@@ -614,6 +647,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         }
         nWalk = __popcll(__ballot(state == ST_WALK));
       } while (nWalk >= p.eventThreshold);
+      STAMP(7);
     }
 
     if (!PRIV) break;
@@ -630,6 +664,9 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
     __syncthreads();
   }
 
+#ifdef MCBRAT_STAMPS
+  if (DEBUG && p.counters && lane == 0) for (int i = 0; i < 9; i++) atomicAdd(p.counters + 16 + i, s_stamp[threadIdx.x >> 6][i]);
+#endif
   if (DEBUG && p.counters) {
     atomicAdd(p.counters + 0, (unsigned long long)cLegs);
     atomicAdd(p.counters + 1, (unsigned long long)cCross);
