@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--parity-photons", type=int, default=100000000)
     ap.add_argument("--event-threshold", type=int, default=0,
                     help="0 = let the library time trial launches (default); >0 fixes it (profiling runs)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="let consecutive steps overlap on the GPU (asynchronous mode of the library: hides each "
+                         "launch's drain; per-kernel durations then include time spent waiting for compute units, so "
+                         "the default run, whose kernel durations rocprofv3 must reproduce, does not use it)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +139,7 @@ def main():
     moments = torch.zeros(8 + 2 * integ.momentsLength(), dtype=torch.float64, device=dev)
     integ.bindMoments(moments.data_ptr())
     rng = new_RandomNumberSequence(10)
+    torch_stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step(i):
         # rank r traces photon ids [ (i*world + r) * per_step, +per_step ): disjoint over ranks and steps
@@ -143,11 +148,17 @@ def main():
         integ.resetMoments()
         integ.computeRadiativeTransfer(dom, rng, photons, ppb, nb)
         if dist is not None:
+            if a.pipeline:  # order the all-reduce after this step's moments and the next reset after the all-reduce
+                integ.streamWaitDone(torch_stream)
             dist.all_reduce(moments, op=dist.ReduceOp.SUM)  # sumAcrossProcesses, monteCarloDriver.f95:1151-1166
-            torch.cuda.synchronize()
-        return integ.lastTraceMs()
+            if a.pipeline:
+                integ.waitStream(torch_stream)
+            else:
+                torch.cuda.synchronize()
+        return 0.0 if a.pipeline else integ.lastTraceMs()
 
     def sync():
+        integ.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -155,6 +166,8 @@ def main():
 
     for i in range(a.warmup):
         step(i)
+        if i == 0 and a.pipeline:
+            integ.setAsync(True)  # after the first call, which chose the event threshold by trial launches
     sync()
     t0 = time.perf_counter()
     kernel_ms = 0.0
@@ -162,6 +175,8 @@ def main():
         kernel_ms += step(a.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
+    if a.pipeline:
+        kernel_ms = integ.lastTraceMs()  # summed over the timed steps (read at the synchronisation above)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -201,14 +216,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s %dx%dx%d, %d photons/GPU/step as %d batches x %d, omega0=0.99 HG g=0.85 mu0=%g"
                        % (a.workload, nx, ny, nz, per_step, nb, ppb, w["mu0"]),
-                       "photons_per_step_per_gpu": per_step, "parallelism": "photon batches sharded over %d GPU(s)" % world},
+                       "photons_per_step_per_gpu": per_step, "parallelism": "photon batches sharded over %d GPU(s)" % world,
+                       "pipelined_steps": bool(a.pipeline)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_photon": bpp, "kernel": "trace_kernel", "kernel_ms_per_launch": launch_ms,
                          "events_per_photon": {k: v / per_step for k, v in cnt.items() if k in ("legs", "crossings", "collisions", "absorbEvents", "topExits", "surfaceHits", "rouletteKills", "rouletteSurvivals")},
                          "lanes_per_walk_iteration": cnt["walkLanes"] / max(1, cnt["walkIterations"]),
                          "lanes_per_event_phase": cnt["eventLanes"] / max(1, cnt["eventPhases"]),
-                         "note": "working set is cache resident; the path is latency/VALU bound (DESIGN.md)"},
+                         "note": "working set is cache resident; the path is latency/VALU bound (DESIGN.md)"
+                                 + ("; --pipeline: kernel durations include waiting for compute units held by the previous launch" if a.pipeline else "")},
         }
         if not a.no_cpu_baseline:
             cb, batches, cols, ccnt, ctot = cpu_baseline(a.workload, a.cpu_photons_per_core, a.cpu_cores)

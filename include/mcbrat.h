@@ -125,6 +125,24 @@ int mcbrat_get_moments(mcbrat_ctx *ctx, double *hostBuffer);
 int mcbrat_enable_counters(mcbrat_ctx *ctx, int32_t enable);
 int mcbrat_get_counters(mcbrat_ctx *ctx, mcbrat_counters *out);
 float mcbrat_last_trace_ms(const mcbrat_ctx *ctx);
+/* Asynchronous mode.  A launch ends with its longest photon history, so every call carries a fixed
+ * drain time; a caller that issues many calls -- the reference's driver calls
+ * computeRadiativeTransfer once per batch, monteCarloDriver.f95:1008 -- can let consecutive calls
+ * overlap: with mcbrat_set_async(ctx, 1), mcbrat_compute_radiative_transfer and mcbrat_reset_moments
+ * only enqueue work (on a small set of HIP streams owned by the context; per-batch results and
+ * moments are still folded in call order, so results are bitwise the same as in synchronous mode)
+ * and return.  Every call that reads results or replaces inputs (report_results, get_moments,
+ * set_*, bind_moments, trace_fates, destroy) synchronises first; mcbrat_synchronize does so
+ * explicitly, after which mcbrat_last_trace_ms is the summed tracing-kernel time of the calls since
+ * the previous synchronisation. */
+int mcbrat_set_async(mcbrat_ctx *ctx, int32_t enable);
+int mcbrat_synchronize(mcbrat_ctx *ctx);
+/* Stream interop for a caller that reduces the bound moment buffer on its own HIP stream (RCCL):
+ * mcbrat_stream_wait_done makes `hipStream` (a hipStream_t) wait for everything enqueued so far;
+ * mcbrat_wait_stream makes the context's next write to the moments wait for what `hipStream` has
+ * enqueued so far.  Neither blocks the host. */
+int mcbrat_stream_wait_done(mcbrat_ctx *ctx, void *hipStream);
+int mcbrat_wait_stream(mcbrat_ctx *ctx, void *hipStream);
 /* Tuning knobs (negative = leave unchanged): workgroups per CU (0 = occupancy query), number of
  * walking lanes below which a wave serves its waiting lanes (0 = choose by timing short trial
  * launches, the default), batches in flight per launch

@@ -56,6 +56,10 @@ SYMBOLS = {
     "mcbrat_enable_counters": (C.c_int, [_vp, _i32]),
     "mcbrat_get_counters": (C.c_int, [_vp, _vp]),
     "mcbrat_last_trace_ms": (_f, [_vp]),
+    "mcbrat_set_async": (C.c_int, [_vp, _i32]),
+    "mcbrat_synchronize": (C.c_int, [_vp]),
+    "mcbrat_stream_wait_done": (C.c_int, [_vp, _vp]),
+    "mcbrat_wait_stream": (C.c_int, [_vp, _vp]),
     "mcbrat_set_tuning": (C.c_int, [_vp] + [_i32] * 8),
     "mcbrat_trace_fates": (C.c_int, [_vp, _u64, _u64, _i64, _vp]),
     "mcbrat_inverse_table_legendre": (C.c_int, [_i32, _vp, _i32, _vp]),

@@ -17,8 +17,28 @@ using namespace mcbrat;
 
 struct mcbrat_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // Per-launch resources.  Synchronous mode uses lane 0 only; asynchronous mode (mcbrat_set_async) rotates
+  // over kLanes so that the drain of one call's tracing kernel overlaps the next call's (a launch ends
+  // with its longest photon history: DESIGN.md section 5, "launch tail").
+  struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the tracing kernel (synchronous mode)
+    hipEvent_t evDone = nullptr;              // after the finish kernels of the lane's latest call
+    unsigned long long *dCounter = nullptr;
+    long long *dSlabs = nullptr;
+    size_t slabCapacity = 0;  // batches
+    float *dColVals = nullptr, *dScalVals = nullptr;
+    size_t finishCapacity = 0;
+  };
+  static constexpr int kLanes = 4;
+  Lane lane[kLanes];
+  int cur = 0, nextLane = 0;
+  bool asyncOn = false;
+  hipEvent_t lastDone = nullptr;   // evDone of the most recent call: the next finish chain waits for it
+  hipEvent_t evExternal = nullptr; // recorded on a caller's stream by mcbrat_wait_stream
+  bool externalPending = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timing, eventPool;  // asynchronous mode: kernel brackets not yet read
+  Lane &L() { return lane[cur]; }
   std::string err;
   int numCUs = 256;
   // grid
@@ -42,11 +62,8 @@ struct mcbrat_ctx {
   int brickMode = 2;               // 0 dense, 1 bricks, 2 automatic
   float *dTables = nullptr;
   double *dVoxelCDF = nullptr;
-  unsigned long long *dCounter = nullptr, *dEventCounters = nullptr;
-  long long *dSlabs = nullptr;
-  size_t slabCapacity = 0;  // batches
-  float *dColVals = nullptr, *dScalVals = nullptr, *dLast = nullptr;
-  size_t finishCapacity = 0;
+  unsigned long long *dEventCounters = nullptr;
+  float *dLast = nullptr;
   double *dMomentsOwned = nullptr, *dMoments = nullptr;
   // tables (host, per component)
   std::vector<std::vector<float>> tables;
@@ -92,6 +109,42 @@ int fail(mcbrat_ctx *c, const std::string &msg) {
     if (e_ != hipSuccess) return fail(c, std::string(#call) + ": " + hipGetErrorString(e_));              \
   } while (0)
 
+int init_lane(mcbrat_ctx *c, int i) {
+  mcbrat_ctx::Lane &L = c->lane[i];
+  if (L.stream) return 0;
+  HIP_OK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+  HIP_OK(c, hipEventCreate(&L.ev0));
+  HIP_OK(c, hipEventCreate(&L.ev1));
+  HIP_OK(c, hipEventCreateWithFlags(&L.evDone, hipEventDisableTiming));
+  HIP_OK(c, hipMalloc((void **)&L.dCounter, sizeof(unsigned long long)));
+  return 0;
+}
+
+// Waits for everything the context has enqueued and reads the kernel brackets of asynchronous calls.
+int sync_all(mcbrat_ctx *c) {
+  for (int i = 0; i < mcbrat_ctx::kLanes; ++i)
+    if (c->lane[i].stream) HIP_OK(c, hipStreamSynchronize(c->lane[i].stream));
+  if (!c->timing.empty()) {
+    float total = 0.f;
+    for (auto &pr : c->timing) {
+      float ms = 0.f;
+      HIP_OK(c, hipEventElapsedTime(&ms, pr.first, pr.second));
+      total += ms;
+      c->eventPool.push_back(pr);
+    }
+    c->timing.clear();
+    c->lastTraceMs = total;
+  }
+  return 0;
+}
+
+int event_pair(mcbrat_ctx *c, std::pair<hipEvent_t, hipEvent_t> &pr) {
+  if (!c->eventPool.empty()) { pr = c->eventPool.back(); c->eventPool.pop_back(); return 0; }
+  HIP_OK(c, hipEventCreate(&pr.first));
+  HIP_OK(c, hipEventCreate(&pr.second));
+  return 0;
+}
+
 double spacing_d(double x) {
   if (x == 0.0) return DBL_MIN;
   int e;
@@ -124,6 +177,7 @@ int ensure_moments(mcbrat_ctx *c) {
 
 int sync_tables(mcbrat_ctx *c) {
   if (!c->tablesDirty) return 0;
+  if (sync_all(c)) return 1;
   std::vector<float> all;
   for (int k = 0; k < c->nc; ++k) {
     if ((int)c->tables.size() <= k || c->tables[k].empty())
@@ -265,7 +319,7 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.dir0[0] = c->dir0[0]; p.dir0[1] = c->dir0[1]; p.dir0[2] = c->dir0[2];
   p.zLaunch = c->zLaunch; p.izLaunch = c->izLaunch;
   p.voxelCDF = c->dVoxelCDF; p.fracAtms = c->fracAtms;
-  p.counter = c->dCounter;
+  p.counter = c->L().dCounter;
   p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
   p.launchThreshold = std::max(1, std::min(64, c->launchThreshold));
   p.surfaceThreshold = std::max(1, std::min(64, c->surfaceThreshold));
@@ -325,7 +379,7 @@ int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
     blocks = std::min(blocks, (p.total + BLOCK - 1) / BLOCK);
   }
   const unsigned grid = (unsigned)std::max<unsigned long long>(1, blocks);
-  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG>), dim3(grid), dim3(BLOCK), lds, c->stream, p);
+  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG>), dim3(grid), dim3(BLOCK), lds, c->L().stream, p);
   HIP_OK(c, hipGetLastError());
   return 0;
 }
@@ -378,13 +432,13 @@ int autotune(mcbrat_ctx *c, DevParams p, unsigned long long ppb, int nBatches) {
     p.eventThreshold = thr;
     float ms = 1e30f;
     for (int rep = 0; rep < 2; ++rep) {  // first repetition warms caches / code
-      HIP_OK(c, hipMemsetAsync(c->dSlabs, 0, sizeof(long long) * p.slabStride * nb, c->stream));
-      HIP_OK(c, hipMemsetAsync(c->dCounter, 0, sizeof(unsigned long long), c->stream));
-      HIP_OK(c, hipEventRecord(c->ev0, c->stream));
+      HIP_OK(c, hipMemsetAsync(c->L().dSlabs, 0, sizeof(long long) * p.slabStride * nb, c->L().stream));
+      HIP_OK(c, hipMemsetAsync(c->L().dCounter, 0, sizeof(unsigned long long), c->L().stream));
+      HIP_OK(c, hipEventRecord(c->L().ev0, c->L().stream));
       if (launch_trace(c, p, false, nb)) return 1;
-      HIP_OK(c, hipEventRecord(c->ev1, c->stream));
-      HIP_OK(c, hipStreamSynchronize(c->stream));
-      HIP_OK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+      HIP_OK(c, hipEventRecord(c->L().ev1, c->L().stream));
+      HIP_OK(c, hipStreamSynchronize(c->L().stream));
+      HIP_OK(c, hipEventElapsedTime(&ms, c->L().ev0, c->L().ev1));
     }
     if (ms < best) { best = ms; bestThr = thr; }
   }
@@ -407,9 +461,7 @@ mcbrat_ctx *mcbrat_create(int device) {
   c->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCUs = prop.multiProcessorCount;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-      hipMalloc((void **)&c->dCounter, sizeof(unsigned long long)) != hipSuccess ||
+  if (init_lane(c, 0) || hipEventCreateWithFlags(&c->evExternal, hipEventDisableTiming) != hipSuccess ||
       hipMalloc((void **)&c->dEventCounters, 32 * sizeof(unsigned long long)) != hipSuccess) {
     delete c;
     return nullptr;
@@ -420,14 +472,21 @@ mcbrat_ctx *mcbrat_create(int device) {
 void mcbrat_destroy(mcbrat_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
-  void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF, c->dCounter,
-                  c->dEventCounters, c->dSlabs, c->dColVals, c->dScalVals, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
+  (void)sync_all(c);
+  void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF,
+                  c->dEventCounters, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
                   c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi};
   for (void *b : bufs) if (b) (void)hipFree(b);
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  for (mcbrat_ctx::Lane &L : c->lane) {
+    void *lb[] = {L.dCounter, L.dSlabs, L.dColVals, L.dScalVals};
+    for (void *b : lb) if (b) (void)hipFree(b);
+    if (L.ev0) (void)hipEventDestroy(L.ev0);
+    if (L.ev1) (void)hipEventDestroy(L.ev1);
+    if (L.evDone) (void)hipEventDestroy(L.evDone);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+  }
+  for (auto &pr : c->eventPool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (c->evExternal) (void)hipEventDestroy(c->evExternal);
   delete c;
 }
 
@@ -442,6 +501,7 @@ int mcbrat_set_grid(mcbrat_ctx *c, int32_t nx, int32_t ny, int32_t nz, const dou
   for (int i = 0; i < nz; ++i) if (!(ze[i + 1] > ze[i])) return fail(c, "new_Domain: z edges must be increasing, unique.");
   if ((long long)nx * ny * nz > 0x7fffffffLL / 2) return fail(c, "new_Integrator: more than 2^30 cells are not supported.");
   (void)hipSetDevice(c->device);
+  if (sync_all(c)) return 1;
   c->nx = nx; c->ny = ny; c->nz = nz;
   c->xe.assign(xe, xe + nx + 1); c->ye.assign(ye, ye + ny + 1); c->ze.assign(ze, ze + nz + 1);
   // regular-spacing flags exactly as new_Integrator :163-181 (deltaX/Y/Z are default-real locals, :140)
@@ -466,7 +526,7 @@ int mcbrat_set_grid(mcbrat_ctx *c, int32_t nx, int32_t ny, int32_t nz, const dou
   c->haveGrid = true; c->haveOptics = false; c->haveSource = false; c->haveLast = false; c->tuned = false;
   if (c->dMomentsOwned) { (void)hipFree(c->dMomentsOwned); c->dMomentsOwned = nullptr; }
   c->dMoments = nullptr;
-  c->slabCapacity = 0; c->finishCapacity = 0;
+  for (mcbrat_ctx::Lane &L : c->lane) L.slabCapacity = L.finishCapacity = 0;  // buffers are re-sized by the next call
   return 0;
 }
 
@@ -477,6 +537,7 @@ int mcbrat_set_optics(mcbrat_ctx *c, int32_t nc, const double *totalExt, const d
   if (nc < 1 || nc > MCBRAT_MAX_COMPONENTS) return fail(c, "getOpticalPropertiesByComponent: unsupported number of components.");
   if (!totalExt || !cumExt || !ssa || !pfIndex) return fail(c, "getOpticalPropertiesByComponent: domain contains no optical components.");
   (void)hipSetDevice(c->device);
+  if (sync_all(c)) return 1;
   const size_t nvox = (size_t)c->nx * c->ny * c->nz;
   std::vector<float> e(nvox), cu(nvox * nc), s(nvox * nc);
   std::vector<uint16_t> pf(nvox * nc);
@@ -573,6 +634,7 @@ int mcbrat_set_source_emission(mcbrat_ctx *c, const double *voxelWeights, double
   if (!c->haveGrid) return fail(c, "setIllumination: domain hasn't been initialized.");
   if (!voxelWeights || !(fracAtmsPower >= 0.0 && fracAtmsPower <= 1.0)) return fail(c, "setIllumination: invalid emission weights.");
   (void)hipSetDevice(c->device);
+  if (sync_all(c)) return 1;
   if (upload(c, &c->dVoxelCDF, voxelWeights, (size_t)c->nx * c->ny * c->nz)) return 1;
   c->fracAtms = fracAtmsPower;
   if (c->srcKind != 1) c->tuned = false;
@@ -586,6 +648,8 @@ int64_t mcbrat_moments_length(const mcbrat_ctx *c) { return c && c->haveGrid ? m
 int mcbrat_bind_moments(mcbrat_ctx *c, double *deviceBuffer) {
   if (!c) return 1;
   if (!c->haveGrid) return fail(c, "bind_moments: set the grid first.");
+  (void)hipSetDevice(c->device);
+  if (sync_all(c)) return 1;
   if (deviceBuffer) c->dMoments = deviceBuffer;
   else { c->dMoments = c->dMomentsOwned; return ensure_moments(c); }
   return 0;
@@ -596,8 +660,15 @@ int mcbrat_reset_moments(mcbrat_ctx *c) {
   if (!c->haveGrid) return fail(c, "reset_moments: set the grid first.");
   (void)hipSetDevice(c->device);
   if (ensure_moments(c)) return 1;
-  HIP_OK(c, hipMemsetAsync(c->dMoments, 0, sizeof(double) * (8 + 2 * (size_t)moments_len(c)), c->stream));
-  HIP_OK(c, hipStreamSynchronize(c->stream));
+  // c->cur is the lane of the latest call: its stream already orders this after every earlier finish chain
+  if (c->externalPending) { HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->evExternal, 0)); c->externalPending = false; }
+  HIP_OK(c, hipMemsetAsync(c->dMoments, 0, sizeof(double) * (8 + 2 * (size_t)moments_len(c)), c->L().stream));
+  if (c->asyncOn) {
+    HIP_OK(c, hipEventRecord(c->L().evDone, c->L().stream));
+    c->lastDone = c->L().evDone;
+    return 0;
+  }
+  HIP_OK(c, hipStreamSynchronize(c->L().stream));
   return 0;
 }
 
@@ -605,7 +676,7 @@ int mcbrat_get_moments(mcbrat_ctx *c, double *host) {
   if (!c || !host) return 1;
   (void)hipSetDevice(c->device);
   if (ensure_moments(c)) return 1;
-  HIP_OK(c, hipStreamSynchronize(c->stream));
+  if (sync_all(c)) return 1;
   HIP_OK(c, hipMemcpy(host, c->dMoments, sizeof(double) * (8 + 2 * (size_t)moments_len(c)), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -621,6 +692,36 @@ int mcbrat_get_counters(mcbrat_ctx *c, mcbrat_counters *out) {
   return 0;
 }
 float mcbrat_last_trace_ms(const mcbrat_ctx *c) { return c ? c->lastTraceMs : 0.f; }
+
+int mcbrat_set_async(mcbrat_ctx *c, int32_t enable) {
+  if (!c) return 1;
+  (void)hipSetDevice(c->device);
+  if (sync_all(c)) return 1;
+  c->asyncOn = enable != 0;
+  c->cur = 0; c->nextLane = 0;
+  return 0;
+}
+
+int mcbrat_synchronize(mcbrat_ctx *c) {
+  if (!c) return 1;
+  (void)hipSetDevice(c->device);
+  return sync_all(c);
+}
+
+int mcbrat_stream_wait_done(mcbrat_ctx *c, void *stream) {
+  if (!c) return 1;
+  (void)hipSetDevice(c->device);
+  if (c->lastDone) HIP_OK(c, hipStreamWaitEvent((hipStream_t)stream, c->lastDone, 0));
+  return 0;
+}
+
+int mcbrat_wait_stream(mcbrat_ctx *c, void *stream) {
+  if (!c) return 1;
+  (void)hipSetDevice(c->device);
+  HIP_OK(c, hipEventRecord(c->evExternal, (hipStream_t)stream));
+  c->externalPending = true;
+  return 0;
+}
 
 int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight,
                       int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold,
@@ -646,36 +747,46 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   if (check_ready(c)) return 1;
   if (ppb < 1 || nBatches < 1) return fail(c, "computeRadiativeTransfer: Didn't process any photons.");
   if (ensure_moments(c)) return 1;
+  const bool async = c->asyncOn && !c->countersOn && !(c->autoTune && !c->tuned);
+  if (!async && sync_all(c)) return 1;
+  if (c->asyncOn) {  // rotate over the lanes
+    c->cur = c->nextLane;
+    c->nextLane = (c->nextLane + 1) % mcbrat_ctx::kLanes;
+    if (init_lane(c, c->cur)) return 1;
+  } else {
+    c->cur = 0;
+  }
   const size_t ncol = (size_t)c->nx * c->ny, nvox = ncol * c->nz;
   const size_t slabStride = 2 * ncol + nvox;
   // batches in flight: bounded by a memory budget (slabs are 8 B per tally bin per batch)
   size_t inFlight = std::max<size_t>(1, (size_t)(4ull << 30) / (slabStride * sizeof(long long)));
   if (c->maxBatchesInFlight > 0) inFlight = std::min<size_t>(inFlight, (size_t)c->maxBatchesInFlight);
   inFlight = std::min<size_t>(inFlight, (size_t)nBatches);
-  if (c->slabCapacity < inFlight) {
-    if (c->dSlabs) (void)hipFree(c->dSlabs);
-    c->dSlabs = nullptr;
-    HIP_OK(c, hipMalloc((void **)&c->dSlabs, sizeof(long long) * slabStride * inFlight));
-    c->slabCapacity = inFlight;
+  if (c->L().slabCapacity < inFlight || c->L().finishCapacity < inFlight) HIP_OK(c, hipStreamSynchronize(c->L().stream));
+  if (c->L().slabCapacity < inFlight) {
+    if (c->L().dSlabs) (void)hipFree(c->L().dSlabs);
+    c->L().dSlabs = nullptr;
+    HIP_OK(c, hipMalloc((void **)&c->L().dSlabs, sizeof(long long) * slabStride * inFlight));
+    c->L().slabCapacity = inFlight;
   }
-  if (c->finishCapacity < inFlight) {
-    if (c->dColVals) (void)hipFree(c->dColVals);
-    if (c->dScalVals) (void)hipFree(c->dScalVals);
-    c->dColVals = c->dScalVals = nullptr;
-    HIP_OK(c, hipMalloc((void **)&c->dColVals, sizeof(float) * 3 * ncol * inFlight));
-    HIP_OK(c, hipMalloc((void **)&c->dScalVals, sizeof(float) * (3 + c->nz) * inFlight));
-    c->finishCapacity = inFlight;
+  if (c->L().finishCapacity < inFlight) {
+    if (c->L().dColVals) (void)hipFree(c->L().dColVals);
+    if (c->L().dScalVals) (void)hipFree(c->L().dScalVals);
+    c->L().dColVals = c->L().dScalVals = nullptr;
+    HIP_OK(c, hipMalloc((void **)&c->L().dColVals, sizeof(float) * 3 * ncol * inFlight));
+    HIP_OK(c, hipMalloc((void **)&c->L().dScalVals, sizeof(float) * (3 + c->nz) * inFlight));
+    c->L().finishCapacity = inFlight;
   }
   if (!c->dLast) HIP_OK(c, hipMalloc((void **)&c->dLast, sizeof(float) * (size_t)moments_len(c)));
 
   DevParams p;
   fill_params(c, p);
   p.seedLo = (uint32_t)seed; p.seedHi = (uint32_t)(seed >> 32);
-  p.slabs = c->dSlabs; p.slabStride = slabStride;
+  p.slabs = c->L().dSlabs; p.slabStride = slabStride;
   p.ppb = (unsigned long long)ppb;
   p.fates = nullptr;
   p.counters = c->countersOn ? c->dEventCounters : nullptr;
-  if (c->countersOn) HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 32 * sizeof(unsigned long long), c->stream));
+  if (c->countersOn) HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 32 * sizeof(unsigned long long), c->L().stream));
 
   if (c->autoTune && !c->tuned) {
     if (autotune(c, p, (unsigned long long)ppb, (int)inFlight)) return 1;
@@ -687,28 +798,39 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     const int nb = std::min<int>((int)inFlight, nBatches - b0);
     p.total = (unsigned long long)ppb * (unsigned long long)nb;
     p.firstPhoton = firstPhotonId + (unsigned long long)b0 * (unsigned long long)ppb;
-    HIP_OK(c, hipMemsetAsync(c->dSlabs, 0, sizeof(long long) * slabStride * nb, c->stream));  // zero tallies :248-252
-    HIP_OK(c, hipMemsetAsync(c->dCounter, 0, sizeof(unsigned long long), c->stream));
-    HIP_OK(c, hipEventRecord(c->ev0, c->stream));
+    HIP_OK(c, hipMemsetAsync(c->L().dSlabs, 0, sizeof(long long) * slabStride * nb, c->L().stream));  // zero tallies :248-252
+    HIP_OK(c, hipMemsetAsync(c->L().dCounter, 0, sizeof(unsigned long long), c->L().stream));
+    std::pair<hipEvent_t, hipEvent_t> bracket(c->L().ev0, c->L().ev1);
+    if (async && event_pair(c, bracket)) return 1;
+    HIP_OK(c, hipEventRecord(bracket.first, c->L().stream));
     if (launch_trace(c, p, c->countersOn, nb)) return 1;
-    HIP_OK(c, hipEventRecord(c->ev1, c->stream));
+    HIP_OK(c, hipEventRecord(bracket.second, c->L().stream));
+    if (async) c->timing.push_back(bracket);
+    if (c->timing.size() > 1024) { if (sync_all(c)) return 1; }  // bound the number of live events
+    // the finish kernels accumulate into one moment array: they run in call order across lanes, and after
+    // whatever a caller's stream did to that array (mcbrat_wait_stream)
+    if (c->lastDone && c->lastDone != c->L().evDone) HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->lastDone, 0));
+    if (c->externalPending) { HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->evExternal, 0)); c->externalPending = false; }
     FinishParams f;
     f.nx = c->nx; f.ny = c->ny; f.nz = c->nz; f.nBatches = nb; f.xyRegular = c->xyRegular;
     f.ppb = p.ppb; f.total = p.total; f.slabStride = slabStride;
-    f.slabs = c->dSlabs; f.relArea = c->dRelArea; f.ze = c->dEdges + (c->nx + 1) + (c->ny + 1);
-    f.colVals = c->dColVals; f.scalVals = c->dScalVals; f.moments = c->dMoments; f.last = c->dLast;
-    hipLaunchKernelGGL(finish_columns, dim3((unsigned)((ncol * (size_t)nb + 255) / 256)), dim3(256), 0, c->stream, f);
-    hipLaunchKernelGGL(finish_column_moments, dim3((unsigned)((3 * ncol + 255) / 256)), dim3(256), 0, c->stream, f);
-    hipLaunchKernelGGL(finish_volume, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, c->stream, f);
-    hipLaunchKernelGGL(finish_reduce, dim3(3 + c->nz, nb), dim3(256), 0, c->stream, f);
-    hipLaunchKernelGGL(finish_scalars, dim3((unsigned)((3 + c->nz + 255) / 256)), dim3(256), 0, c->stream, f);
+    f.slabs = c->L().dSlabs; f.relArea = c->dRelArea; f.ze = c->dEdges + (c->nx + 1) + (c->ny + 1);
+    f.colVals = c->L().dColVals; f.scalVals = c->L().dScalVals; f.moments = c->dMoments; f.last = c->dLast;
+    hipLaunchKernelGGL(finish_columns, dim3((unsigned)((ncol * (size_t)nb + 255) / 256)), dim3(256), 0, c->L().stream, f);
+    hipLaunchKernelGGL(finish_column_moments, dim3((unsigned)((3 * ncol + 255) / 256)), dim3(256), 0, c->L().stream, f);
+    hipLaunchKernelGGL(finish_volume, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, c->L().stream, f);
+    hipLaunchKernelGGL(finish_reduce, dim3(3 + c->nz, nb), dim3(256), 0, c->L().stream, f);
+    hipLaunchKernelGGL(finish_scalars, dim3((unsigned)((3 + c->nz + 255) / 256)), dim3(256), 0, c->L().stream, f);
     HIP_OK(c, hipGetLastError());
-    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipEventRecord(c->L().evDone, c->L().stream));
+    c->lastDone = c->L().evDone;
+    if (async) continue;
+    HIP_OK(c, hipStreamSynchronize(c->L().stream));
     float ms = 0.f;
-    HIP_OK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    HIP_OK(c, hipEventElapsedTime(&ms, c->L().ev0, c->L().ev1));
     traceMs += ms;
   }
-  c->lastTraceMs = traceMs;
+  if (!async) c->lastTraceMs = traceMs;
   if (c->countersOn) {
     unsigned long long h[16];
     HIP_OK(c, hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost));
@@ -738,6 +860,7 @@ int mcbrat_report_results(mcbrat_ctx *c, float *meanUp, float *meanDown, float *
   if (!c) return 1;
   if (!c->haveLast) return fail(c, "reportResults: no batch has been traced yet.");
   (void)hipSetDevice(c->device);
+  if (sync_all(c)) return 1;
   const size_t ncol = (size_t)c->nx * c->ny, nvox = ncol * c->nz;
   std::vector<float> h((size_t)moments_len(c));
   HIP_OK(c, hipMemcpy(h.data(), c->dLast, sizeof(float) * h.size(), hipMemcpyDeviceToHost));
@@ -757,16 +880,17 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
   (void)hipSetDevice(c->device);
   if (check_ready(c)) return 1;
   if (n < 1 || !fates) return fail(c, "trace_fates: nothing to trace.");
+  if (sync_all(c)) return 1;
   const size_t ncol = (size_t)c->nx * c->ny, nvox = ncol * c->nz;
   const size_t slabStride = 2 * ncol + nvox;
   long long *scratch = nullptr;
   mcbrat_fate *dF = nullptr;
   HIP_OK(c, hipMalloc((void **)&scratch, sizeof(long long) * slabStride));
   HIP_OK(c, hipMalloc((void **)&dF, sizeof(mcbrat_fate) * (size_t)n));
-  HIP_OK(c, hipMemsetAsync(scratch, 0, sizeof(long long) * slabStride, c->stream));
-  HIP_OK(c, hipMemsetAsync(dF, 0xff, sizeof(mcbrat_fate) * (size_t)n, c->stream));
-  HIP_OK(c, hipMemsetAsync(c->dCounter, 0, sizeof(unsigned long long), c->stream));
-  HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 32 * sizeof(unsigned long long), c->stream));
+  HIP_OK(c, hipMemsetAsync(scratch, 0, sizeof(long long) * slabStride, c->L().stream));
+  HIP_OK(c, hipMemsetAsync(dF, 0xff, sizeof(mcbrat_fate) * (size_t)n, c->L().stream));
+  HIP_OK(c, hipMemsetAsync(c->L().dCounter, 0, sizeof(unsigned long long), c->L().stream));
+  HIP_OK(c, hipMemsetAsync(c->dEventCounters, 0, 32 * sizeof(unsigned long long), c->L().stream));
   DevParams p;
   fill_params(c, p);
   p.seedLo = (uint32_t)seed; p.seedHi = (uint32_t)(seed >> 32);
@@ -777,13 +901,13 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
   const int traceCap = 4096;
   if (const char *tp = getenv("MCBRAT_TRACE_PHOTON")) {  // development aid: per-collision records of one photon
     HIP_OK(c, hipMalloc((void **)&dTrace, sizeof(double) * 12 * traceCap));
-    HIP_OK(c, hipMemsetAsync(dTrace, 0, sizeof(double) * 12 * traceCap, c->stream));
+    HIP_OK(c, hipMemsetAsync(dTrace, 0, sizeof(double) * 12 * traceCap, c->L().stream));
     p.traceBuf = dTrace; p.traceIndex = strtoull(tp, nullptr, 10); p.traceCap = traceCap;
   }
   int rc = launch_trace(c, p, true, 1);
   if (!rc && dTrace) {
     std::vector<double> h(12 * traceCap);
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->L().stream);
     (void)hipMemcpy(h.data(), dTrace, sizeof(double) * h.size(), hipMemcpyDeviceToHost);
     for (int i = 0; i < traceCap && h[12 * i] > 0; ++i)
       fprintf(stderr, "GPUTRACE %d ev %.0f cell %.0f %.0f %.0f pos %.17g %.17g %.17g dir %.9g %.9g %.9g tau %.9g w %.9g\n", i, h[12 * i],
@@ -792,7 +916,7 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
     (void)hipFree(dTrace);
   }
   if (!rc) {
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = hipStreamSynchronize(c->L().stream);
     if (e == hipSuccess) e = hipMemcpy(fates, dF, sizeof(mcbrat_fate) * (size_t)n, hipMemcpyDeviceToHost);
     unsigned long long h[16];
     if (e == hipSuccess) e = hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost);

@@ -108,6 +108,21 @@ class Integrator:
         self._check(self._lib.mcbrat_set_tuning(self._ctx, blocksPerCU, eventThreshold, maxBatchesInFlight,
                                                 privateTallies, blockSize, launchThreshold, surfaceThreshold, brickLayout))
 
+    def setAsync(self, enable=True):
+        """Let consecutive computeRadiativeTransfer / resetMoments calls overlap on the GPU (include/mcbrat.h)."""
+        self._check(self._lib.mcbrat_set_async(self._ctx, int(bool(enable))))
+
+    def synchronize(self):
+        self._check(self._lib.mcbrat_synchronize(self._ctx))
+
+    def streamWaitDone(self, hip_stream):
+        """Make a caller's HIP stream (raw handle, e.g. torch.cuda.current_stream().cuda_stream) wait for the work enqueued so far."""
+        self._check(self._lib.mcbrat_stream_wait_done(self._ctx, C.c_void_p(hip_stream)))
+
+    def waitStream(self, hip_stream):
+        """Make the next write to the moments wait for what the caller's HIP stream has enqueued so far."""
+        self._check(self._lib.mcbrat_wait_stream(self._ctx, C.c_void_p(hip_stream)))
+
     # -- computeRadiativeTransfer -------------------------------------------------------
     def _load_domain(self, dom):
         token = (id(dom), id(dom.totalExt), self.minInverseTableSize)

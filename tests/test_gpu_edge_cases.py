@@ -158,3 +158,41 @@ def test_brick_layout_is_lossless(M):
     _, _, last, _ = _run(M, odd, 0.7, 120.0, 20000, 1, tuning=dict(brickLayout=1))
     for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
         assert abs(last[k] - ref[k]) < 2e-3, (k, last[k], ref[k])
+
+
+def test_async_calls_overlap_and_match_synchronous_mode(M):
+    """The reference's driver calls computeRadiativeTransfer once per batch (monteCarloDriver.f95:1008).
+    In asynchronous mode those calls overlap on the GPU; moments are folded in call order, so they must
+    be bitwise what the synchronous calls give -- also with a reset in between and a ragged last call."""
+    import time
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.step_cloud(0.99)
+    dom = cases.product_domain(case)
+    photons = M.new_PhotonStream(1.0, 0.0, numberOfPhotons=10 ** 12)
+    out = {}
+    for mode in ("sync", "async"):
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001)
+        integ.setTuning(eventThreshold=16)
+        integ.setAsync(mode == "async")
+        rng = new_RandomNumberSequence(SEED)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, rng, photons, 20000, 3)   # discarded by the reset below
+        integ.resetMoments()
+        integ.synchronize()
+        t0 = time.time()
+        for k in range(40):
+            integ.computeRadiativeTransfer(dom, rng, photons, 50000 if k < 39 else 12345, 1)
+        integ.synchronize()
+        dt = time.time() - t0
+        out[mode] = (integ.moments(), integ.reportResults(), dt, integ.lastTraceMs())
+        integ.finalize()
+    ms, rs, ts, ks = out["sync"]
+    ma, ra, ta, ka = out["async"]
+    assert ms[0] == ma[0] == 39 * 50000 + 12345 and ms[1] == ma[1] == 40
+    assert np.array_equal(ms, ma)
+    for k in rs:
+        assert np.array_equal(np.asarray(rs[k]), np.asarray(ra[k])), k
+    assert ka > 0.0
+    print("40 per-batch calls: synchronous %.1f ms, asynchronous %.1f ms (kernel time %.1f / %.1f ms)" % (ts * 1e3, ta * 1e3, ks, ka))
+    assert ta < ts  # the drain of one call overlaps the next
