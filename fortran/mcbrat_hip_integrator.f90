@@ -25,7 +25,7 @@ module mcbrat_hip_integrator
             setOpticalProperties, setInverseTable, setSolarSource, setEmissionSource, &
             specifyParameters, computeRadiativeTransfer, reportResults, &
             resetMoments, getMoments, momentsLength, lastMessage, &
-            inverseTableLegendre, lastTraceMilliseconds
+            inverseTableLegendre, lastTraceMilliseconds, setAsynchronous, synchronize
 
   interface
     function mcbrat_create(device) bind(C, name="mcbrat_create") result(ctx)
@@ -116,6 +116,17 @@ module mcbrat_hip_integrator
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: ctx
       real(c_double), intent(out) :: buf(*)
+      integer(c_int) :: rc
+    end function
+    function mcbrat_set_async(ctx, enable) bind(C, name="mcbrat_set_async") result(rc)
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: enable
+      integer(c_int) :: rc
+    end function
+    function mcbrat_synchronize(ctx) bind(C, name="mcbrat_synchronize") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
       integer(c_int) :: rc
     end function
     function mcbrat_last_trace_ms(ctx) bind(C, name="mcbrat_last_trace_ms") result(ms)
@@ -274,6 +285,19 @@ contains
     integer, intent(out) :: ierr
     ierr = mcbrat_get_moments(this%ctx, buffer)
   end subroutine getMoments
+  ! Per-batch callers (the driver's loop, monteCarloDriver.f95:1008): let consecutive calls overlap on the GPU;
+  ! reportResults / getMoments synchronise by themselves.
+  subroutine setAsynchronous(this, enable, ierr)
+    type(integrator), intent(inout) :: this
+    logical, intent(in) :: enable
+    integer, intent(out) :: ierr
+    ierr = mcbrat_set_async(this%ctx, merge(1_c_int32_t, 0_c_int32_t, enable))
+  end subroutine setAsynchronous
+  subroutine synchronize(this, ierr)
+    type(integrator), intent(inout) :: this
+    integer, intent(out) :: ierr
+    ierr = mcbrat_synchronize(this%ctx)
+  end subroutine synchronize
   real function lastTraceMilliseconds(this)
     type(integrator), intent(in) :: this
     lastTraceMilliseconds = mcbrat_last_trace_ms(this%ctx)

@@ -699,6 +699,9 @@ int mcbrat_set_async(mcbrat_ctx *c, int32_t enable) {
   if (sync_all(c)) return 1;
   c->asyncOn = enable != 0;
   c->cur = 0; c->nextLane = 0;
+  if (c->asyncOn)
+    for (int i = 0; i < mcbrat_ctx::kLanes; ++i)
+      if (init_lane(c, i)) return 1;
   return 0;
 }
 
@@ -762,20 +765,26 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   size_t inFlight = std::max<size_t>(1, (size_t)(4ull << 30) / (slabStride * sizeof(long long)));
   if (c->maxBatchesInFlight > 0) inFlight = std::min<size_t>(inFlight, (size_t)c->maxBatchesInFlight);
   inFlight = std::min<size_t>(inFlight, (size_t)nBatches);
-  if (c->L().slabCapacity < inFlight || c->L().finishCapacity < inFlight) HIP_OK(c, hipStreamSynchronize(c->L().stream));
-  if (c->L().slabCapacity < inFlight) {
-    if (c->L().dSlabs) (void)hipFree(c->L().dSlabs);
-    c->L().dSlabs = nullptr;
-    HIP_OK(c, hipMalloc((void **)&c->L().dSlabs, sizeof(long long) * slabStride * inFlight));
-    c->L().slabCapacity = inFlight;
-  }
-  if (c->L().finishCapacity < inFlight) {
-    if (c->L().dColVals) (void)hipFree(c->L().dColVals);
-    if (c->L().dScalVals) (void)hipFree(c->L().dScalVals);
-    c->L().dColVals = c->L().dScalVals = nullptr;
-    HIP_OK(c, hipMalloc((void **)&c->L().dColVals, sizeof(float) * 3 * ncol * inFlight));
-    HIP_OK(c, hipMalloc((void **)&c->L().dScalVals, sizeof(float) * (3 + c->nz) * inFlight));
-    c->L().finishCapacity = inFlight;
+  // asynchronous mode sizes every lane at once: allocation synchronises the device, so it must not recur
+  for (int li = 0; li < mcbrat_ctx::kLanes; ++li) {
+    mcbrat_ctx::Lane &L = c->lane[li];
+    if (li != c->cur && !(c->asyncOn && L.stream)) continue;
+    if (L.slabCapacity >= inFlight && L.finishCapacity >= inFlight) continue;
+    HIP_OK(c, hipStreamSynchronize(L.stream));
+    if (L.slabCapacity < inFlight) {
+      if (L.dSlabs) (void)hipFree(L.dSlabs);
+      L.dSlabs = nullptr;
+      HIP_OK(c, hipMalloc((void **)&L.dSlabs, sizeof(long long) * slabStride * inFlight));
+      L.slabCapacity = inFlight;
+    }
+    if (L.finishCapacity < inFlight) {
+      if (L.dColVals) (void)hipFree(L.dColVals);
+      if (L.dScalVals) (void)hipFree(L.dScalVals);
+      L.dColVals = L.dScalVals = nullptr;
+      HIP_OK(c, hipMalloc((void **)&L.dColVals, sizeof(float) * 3 * ncol * inFlight));
+      HIP_OK(c, hipMalloc((void **)&L.dScalVals, sizeof(float) * (3 + c->nz) * inFlight));
+      L.finishCapacity = inFlight;
+    }
   }
   if (!c->dLast) HIP_OK(c, hipMalloc((void **)&c->dLast, sizeof(float) * (size_t)moments_len(c)));
 
