@@ -670,11 +670,175 @@ static void find_xy_indices(const orc_problem *P, const grid_flags *G, double xP
 }
 
 /* ------------------------------------------------------------------------ */
+/* radiance by local estimation                                              */
+/* ------------------------------------------------------------------------ */
+void orc_intensity_directions(int n, const float *mus, const float *phisDeg, float *dirs) { /* :1270-1272 */
+  const float Pi = 3.14159265358979312f;
+  for (int i = 0; i < n; i++) make_direction_cosines(mus[i], phisDeg[i] * Pi / 180.0f, dirs + 3 * i);
+}
+
+void orc_forward_angles(int nAngles, float *angles) { /* opticalProperties.f95:1914 */
+  const float Pi = 3.14159265358979312f;
+  for (int j = 0; j < nAngles; j++) angles[j] = ((float)j / (float)(nAngles - 1)) * Pi;
+}
+
+/* computeNormalization, opticalProperties.f95:2026-2050 (1-based transitionIndex) */
+static float hybrid_normalization(int nAngles, const float *angleCosines, const float *values,
+                                  const float *gaussianValues, int transitionIndex) {
+  float integralGaus = 0.0f, integralOrig = 0.0f;
+  for (int k = 1; k <= transitionIndex - 1; k++)
+    integralGaus += (0.5f * (gaussianValues[k - 1] + gaussianValues[k])) * (angleCosines[k - 1] - angleCosines[k]);
+  for (int k = transitionIndex; k <= nAngles - 1; k++)
+    integralOrig += (0.5f * (values[k - 1] + values[k])) * (angleCosines[k - 1] - angleCosines[k]);
+  if (integralOrig >= 2.0f) return 1.0f / integralGaus;
+  return (2.0f - integralOrig) / integralGaus;
+}
+static float hybrid_diff(int nAngles, const float *angleCosines, const float *values, const float *gaussianValues,
+                         int transitionIndex) { /* phaseFuncDiff :2011-2024 */
+  float P0 = hybrid_normalization(nAngles, angleCosines, values, gaussianValues, transitionIndex);
+  return P0 * gaussianValues[transitionIndex - 1] - values[transitionIndex - 1];
+}
+
+void orc_hybrid_phase_functions(int nAngles, int nEntries, const float *angles, const float *values,
+                                float gaussianWidthDeg, float *newValues) { /* :1937-2009 */
+  const float Pi = 3.14159265358979312f;
+  float *gaus = (float *)malloc(sizeof(float) * nAngles), *cosA = (float *)malloc(sizeof(float) * nAngles);
+  for (int k = 0; k < nAngles; k++) {
+    cosA[k] = cosf(angles[k]);
+    float x = angles[k] / (gaussianWidthDeg * Pi / 180.0f);
+    gaus[k] = expf(-(x * x));
+  }
+  memcpy(newValues, values, sizeof(float) * (size_t)nAngles * nEntries);
+  for (int e = 0; e < nEntries; e++) {
+    const float *v = values + (size_t)e * nAngles;
+    float *nv = newValues + (size_t)e * nAngles;
+    int lowerBound = orc_find_index_real(gaussianWidthDeg * Pi / 180.0f, angles, nAngles, 0) + 1;
+    if (lowerBound >= nAngles - 2) break; /* exit entryLoop */
+    float lowDiff = hybrid_diff(nAngles, cosA, v, gaus, lowerBound), upDiff = 0.0f;
+    int increment = 1, upperBound = lowerBound, noRoot = 0;
+    for (;;) { /* huntingLoop */
+      upperBound = lowerBound + increment < nAngles - 1 ? lowerBound + increment : nAngles - 1;
+      upDiff = hybrid_diff(nAngles, cosA, v, gaus, upperBound);
+      if (lowerBound == nAngles - 1) { noRoot = 1; break; }
+      if (lowDiff * upDiff < 0.0f) break;
+      lowerBound = upperBound;
+      lowDiff = upDiff;
+      increment *= 2;
+    }
+    if (noRoot) continue; /* cycle entryLoop: keep the original phase function */
+    for (;;) { /* bisectionLoop */
+      if (upperBound <= lowerBound + 1) break;
+      int midPoint = (lowerBound + upperBound) / 2;
+      float midDiff = hybrid_diff(nAngles, cosA, v, gaus, midPoint);
+      if (midDiff * upDiff < 0.0f) { lowerBound = midPoint; lowDiff = midDiff; }
+      else { upperBound = midPoint; upDiff = midDiff; }
+    }
+    int transitionIndex = lowerBound;
+    float P0 = hybrid_normalization(nAngles, cosA, v, gaus, transitionIndex);
+    for (int k = 0; k < transitionIndex; k++) nv[k] = P0 * gaus[k];
+  }
+  free(gaus); free(cosA);
+}
+
+float orc_lookup_phase_value(const float *table, int nAngleSteps, float scatteringAngle) { /* :1835-1870 */
+  const float Pi = 3.14159265358979312f;
+  float deltaTheta = Pi / (float)(nAngleSteps - 1);
+  int angleIndex = (int)(scatteringAngle / deltaTheta) + 1;
+  if (angleIndex < nAngleSteps) {
+    float weight = 1.0f - (scatteringAngle - (float)(angleIndex - 1) * deltaTheta) / deltaTheta;
+    return weight * table[angleIndex - 1] + (1.0f - weight) * table[angleIndex];
+  }
+  return table[nAngleSteps - 1];
+}
+
+/* computeIntensityContribution :1623-1832.  Philox slots: direction i of event e uses block
+ * 0x100 + i = [tauFree, roulette, -, -]. */
+static void intensity_contribution(const orc_problem *P, const orc_intensity *I, orc_rng *R, float photonWeight,
+                                   double xPos, double yPos, double zPos, int xIndex, int yIndex, int zIndex,
+                                   const float dir[3], int component, int scatteringOrder, float *contributions,
+                                   int *xIndexF, int *yIndexF, float *intensityExcess) {
+  const float Pi = 3.14159265358979312f;
+  const int nDir = I->nDirections;
+  const int zIndexMax = P->nz + 1; /* size(zPosition) */
+  for (int i = 0; i < nDir; i++) {
+    const float *D = I->directions + 3 * i;
+    float normalizedPhaseFunc;
+    if (component == 0) normalizedPhaseFunc = 1.0f / Pi;                            /* :1691 Lambertian surface */
+    else if (component < 0) normalizedPhaseFunc = 1.0f / ((4.0f * Pi) * fabsf(D[2])); /* :1696 isotropic emission */
+    else {
+      float projection = dir[0] * D[0] + dir[1] * D[1] + dir[2] * D[2]; /* :1704 */
+      if (fabsf(projection) > 1.0f) projection = copysignf(1.0f, projection);
+      float scatteringAngle = acosf(projection);
+      int pfi = P->pfIndex[IDX4(P, xIndex, yIndex, zIndex, component)];
+      int nA = I->fwdNAngles[component - 1];
+      const float *base = (I->useHybrid && scatteringOrder <= I->numOrdersOrig) ? I->fwdOrigTables : I->fwdTables;
+      float val = orc_lookup_phase_value(base + I->fwdOffset[component - 1] + (size_t)(pfi - 1) * nA, nA, scatteringAngle);
+      normalizedPhaseFunc = val / ((4.0f * Pi) * fabsf(D[2])); /* :1726 */
+    }
+    double pos[3] = {xPos, yPos, zPos};
+    int32_t idx[3] = {xIndex, yIndex, zIndex};
+    float contribution;
+    if (!I->useRussianRoulette) { /* :1729-1752 */
+      float tau = orc_accumulate_extinction(P, D, pos, idx, 0, 0.0f, NULL);
+      contribution = tau >= 0.0f ? (photonWeight * normalizedPhaseFunc) * expf(-tau) : 0.0f;
+    } else { /* Iwabuchi 2006 :1753-1813 */
+      float u = draw(R, 0x100u + (uint32_t)i, 0);
+      float tauFree = -logf(u > FLT_MIN ? u : FLT_MIN);
+      if (Pi * normalizedPhaseFunc <= I->zetaMin) {
+        (void)orc_accumulate_extinction(P, D, pos, idx, 1, tauFree, NULL);
+        float u2 = draw(R, 0x100u + (uint32_t)i, 1);
+        if (u2 <= Pi * normalizedPhaseFunc / I->zetaMin && idx[2] >= zIndexMax) contribution = photonWeight * I->zetaMin / Pi;
+        else contribution = 0.0f;
+      } else {
+        float m = Pi * normalizedPhaseFunc;
+        float tauMax = -logf(I->zetaMin / (m > FLT_MIN ? m : FLT_MIN));
+        float tau = orc_accumulate_extinction(P, D, pos, idx, 1, tauMax, NULL);
+        if (idx[2] >= zIndexMax && tau >= 0.0f) {
+          contribution = (photonWeight * normalizedPhaseFunc) * expf(-tau);
+        } else if (tau >= 0.0f) {
+          (void)orc_accumulate_extinction(P, D, pos, idx, 1, tauFree, NULL);
+          contribution = idx[2] >= zIndexMax ? photonWeight * I->zetaMin / Pi : 0.0f;
+        } else {
+          contribution = 0.0f;
+        }
+      }
+    }
+    if (I->limitContributions && contribution > I->maxContribution) { /* :1815-1826 */
+      const int cc = component < 0 ? 0 : component; /* (the reference indexes intensityExcess(:, -1) out of bounds) */
+      if (intensityExcess) intensityExcess[(size_t)cc * nDir + i] += contribution - I->maxContribution;
+      contribution = I->maxContribution;
+    }
+    contributions[i] = contribution;
+    /* the column the ray leaves through; a ray stopped inside keeps its last cell */
+    xIndexF[i] = idx[0] < 1 ? 1 : (idx[0] > P->nx ? P->nx : idx[0]);
+    yIndexF[i] = idx[1] < 1 ? 1 : (idx[1] > P->ny ? P->ny : idx[1]);
+  }
+}
+
+static void add_intensity(const orc_problem *P, const orc_intensity *I, const float *contributions, const int *xF,
+                          const int *yF, int component, float *intensity, float *byComponent) {
+  const size_t ncol = (size_t)P->nx * P->ny;
+  for (int i = 0; i < I->nDirections; i++) { /* :535-540, :696-701, :785-790 */
+    size_t b = (size_t)(xF[i] - 1) + (size_t)P->nx * (yF[i] - 1) + ncol * i;
+    intensity[b] += contributions[i];
+    if (byComponent) byComponent[(size_t)component * I->nDirections * ncol + b] += contributions[i];
+  }
+}
+
+/* ------------------------------------------------------------------------ */
 /* computeRT :393-841                                                        */
 /* ------------------------------------------------------------------------ */
 int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, int64_t numPhotons,
                        float *fluxUp, float *fluxDown, float *fluxAbsorbed, float *volumeAbsorption,
                        orc_counters *C, orc_fate *fates) {
+  return orc_compute_rt_intensity(P, S, R, numPhotons, fluxUp, fluxDown, fluxAbsorbed, volumeAbsorption, C, fates,
+                                  NULL, NULL, NULL, NULL);
+}
+
+int64_t orc_compute_rt_intensity(const orc_problem *P, const orc_source *S, orc_rng *R, int64_t numPhotons,
+                                 float *fluxUp, float *fluxDown, float *fluxAbsorbed, float *volumeAbsorption,
+                                 orc_counters *C, orc_fate *fates, const orc_intensity *I, float *intensity,
+                                 float *intensityByComponent, float *intensityExcess) {
   const int nx = P->nx, ny = P->ny, nz = P->nz, nc = P->nc;
   const size_t ncol = (size_t)nx * ny, nvox = ncol * nz;
   const float Pi = 3.14159265358979312f; /* :31 */
@@ -685,6 +849,17 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
   memset(fluxDown, 0, sizeof(float) * ncol);
   memset(fluxAbsorbed, 0, sizeof(float) * ncol);
   memset(volumeAbsorption, 0, sizeof(float) * nvox);
+  const int nDir = (I && intensity) ? I->nDirections : 0;
+  float *contributions = NULL;
+  int *xIndexF = NULL, *yIndexF = NULL;
+  if (nDir > 0) { /* :257-261, :452-455 */
+    memset(intensity, 0, sizeof(float) * ncol * nDir);
+    if (intensityByComponent) memset(intensityByComponent, 0, sizeof(float) * ncol * nDir * (nc + 1));
+    if (intensityExcess) memset(intensityExcess, 0, sizeof(float) * nDir * (nc + 1));
+    contributions = (float *)malloc(sizeof(float) * nDir);
+    xIndexF = (int *)malloc(sizeof(int) * nDir);
+    yIndexF = (int *)malloc(sizeof(int) * nDir);
+  }
 
   grid_flags G;
   orc_grid_flags(P, &G.xyRegular, &G.zRegular, &G.dX, &G.dY, &G.dZ);
@@ -742,6 +917,11 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
         size_t v3 = IDX3(P, xIndex, yIndex, zIndex);
         volumeAbsorption[v3] = volumeAbsorption[v3] - 1.0f;
       }
+      if (nDir > 0) { /* :510-541 emission seen directly: surface (component 0) or atmosphere (-1) */
+        intensity_contribution(P, I, R, photonWeight, xPos, yPos, zPos, xIndex, yIndex, zIndex, dir,
+                               zPos == 0.0 ? 0 : -1, scatteringOrder, contributions, xIndexF, yIndexF, intensityExcess);
+        add_intensity(P, I, contributions, xIndexF, yIndexF, 0, intensity, intensityByComponent);
+      }
     }
     int fate = -1;
     float fateWeight = 0.0f;
@@ -779,6 +959,11 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
         photonWeight = (float)((double)photonWeight * albedo); /* :673 */
         if (photonWeight <= FLT_MIN) { cnt.surfaceAbsorbed++; fate = 1; fateWeight = wBefore; break; }
         make_direction_cosines(mu, phi, dir);
+        if (nDir > 0) { /* :680-702 */
+          intensity_contribution(P, I, R, photonWeight, xPos, yPos, zPos, xIndex, yIndex, zIndex, dir, 0,
+                                 scatteringOrder, contributions, xIndexF, yIndexF, intensityExcess);
+          add_intensity(P, I, contributions, xIndexF, yIndexF, 0, intensity, intensityByComponent);
+        }
       } else { /* scattering event :703-821 */
         if (tracePhoton >= 0 && ip == tracePhoton) /* development aid: ORC_TRACE_PHOTON=<index> */
           fprintf(stderr, "ORCTRACE %d ev %u cell %d %d %d pos %.17g %.17g %.17g dir %.9g %.9g %.9g tau %.9g w %.9g\n", scatteringOrder,
@@ -826,6 +1011,11 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
           photonWeight = photonWeight * ssa;
           cnt.absorbEvents++;
         }
+        if (nDir > 0) { /* :776-790 */
+          intensity_contribution(P, I, R, photonWeight, xPos, yPos, zPos, xIndex, yIndex, zIndex, dir, component,
+                                 scatteringOrder, contributions, xIndexF, yIndexF, intensityExcess);
+          add_intensity(P, I, contributions, xIndexF, yIndexF, component, intensity, intensityByComponent);
+        }
         if (P->useRussianRoulette && photonWeight < RussianRouletteW / 2.0f) { /* :805-811 */
           if (draw(R, 1, 1) >= photonWeight / RussianRouletteW) /* block 1 elem 1 */ { photonWeight = 0.0f; cnt.rouletteKills++; }
           else { photonWeight = RussianRouletteW; cnt.rouletteSurvivals++; }
@@ -849,7 +1039,42 @@ int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R, in
   cnt.draws = R->ndraws - drawsAtStart;
   if (C) *C = cnt;
   free(stream);
+  free(contributions); free(xIndexF); free(yIndexF);
   return nPhotons;
+}
+
+void orc_normalize_intensity(const orc_problem *P, const orc_intensity *I, int64_t numPhotonsProcessed,
+                             float *intensity, float *intensityByComponent, const float *intensityExcess) {
+  const int nx = P->nx, ny = P->ny, nc = P->nc, nDir = I->nDirections;
+  const size_t ncol = (size_t)nx * ny;
+  if (I->limitContributions && intensityByComponent && intensityExcess) { /* :294-320 */
+    for (int j = 0; j <= nc; j++)
+      for (int d = 0; d < nDir; d++) {
+        float ex = intensityExcess[(size_t)j * nDir + d];
+        if (ex > 0.0f) {
+          float *bc = intensityByComponent + ((size_t)j * nDir + d) * ncol;
+          float sum = 0.0f;
+          for (size_t i = 0; i < ncol; i++) sum += bc[i];
+          for (size_t i = 0; i < ncol; i++) intensity[(size_t)d * ncol + i] += (bc[i] / sum) * ex;
+          for (size_t i = 0; i < ncol; i++) bc[i] = bc[i] + (bc[i] / sum) * ex;
+        }
+      }
+  }
+  grid_flags G;
+  orc_grid_flags(P, &G.xyRegular, &G.zRegular, &G.dX, &G.dY, &G.dZ);
+  for (int j = 0; j < ny; j++)
+    for (int i = 0; i < nx; i++) { /* :331-342, :369-379 */
+      float nppc;
+      if (G.xyRegular) nppc = (float)numPhotonsProcessed / (float)(nx * ny);
+      else {
+        double rel = ((P->ye[j + 1] - P->ye[j]) * (P->xe[i + 1] - P->xe[i])) / ((P->xe[nx] - P->xe[0]) * (P->ye[ny] - P->ye[0]));
+        nppc = (float)rel * (float)numPhotonsProcessed;
+      }
+      size_t c2 = (size_t)i + (size_t)nx * j;
+      for (int d = 0; d < nDir; d++) intensity[(size_t)d * ncol + c2] /= nppc;
+      if (intensityByComponent)
+        for (int k = 0; k < (nc + 1) * nDir; k++) intensityByComponent[(size_t)k * ncol + c2] /= nppc;
+    }
 }
 
 /* computeRadiativeTransfer :328-364 */

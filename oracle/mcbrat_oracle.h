@@ -130,6 +130,48 @@ int orc_emission_weighting(int nx, int ny, int nz, int nc, const double *xe, con
                            double lambda_um, double sfcTemp, double dLambda,
                            double *voxelWeights, double *fracAtmsPower, double *totalFlux);
 
+/* ---- radiance by local estimation (monteCarloRadiativeTransfer.f95:1623-1870) ---- */
+/* What specifyParameters (:1236-1292) and tabulateForwardPhaseFunctions
+ * (opticalProperties.f95:1872-1935) leave in the integrator / domain. */
+typedef struct {
+  int32_t nDirections;
+  const float *directions;           /* [nDir][3] makeDirectionCosines(mu, phi*Pi/180) :1270-1272 */
+  const float *fwdTables;            /* tabulatedPhaseFunctions: components concatenated, [entry][angle] */
+  const float *fwdOrigTables;        /* tabulatedOrigPhaseFunctions, same layout */
+  const int64_t *fwdOffset;          /* [nc] float offset of a component's table */
+  const int32_t *fwdNAngles;         /* [nc] angles per entry (equally spaced 0..pi) */
+  int32_t useHybrid;                 /* useHybridPhaseFunsForIntenCalcs */
+  int32_t numOrdersOrig;             /* numOrdersOrigPhaseFunIntenCalcs */
+  int32_t useRussianRoulette;        /* useRussianRouletteForIntensity */
+  float zetaMin;
+  int32_t limitContributions;        /* limitIntensityContributions */
+  float maxContribution;
+} orc_intensity;
+
+/* makeDirectionCosines(mu, phiDegrees * Pi/180) for the intensity directions (:1270-1272). */
+void orc_intensity_directions(int n, const float *mus, const float *phisDeg, float *dirs);
+/* tabulateForwardPhaseFunctions: values of nEntries phase functions at nAngles equally spaced
+ * angles (opticalProperties.f95:1914-1916).  Legendre storage (coefficients chi_1.. per entry,
+ * ragged via start/length) or angle-value storage share orc_phase_values_*; this helper only
+ * makes the angle grid. */
+void orc_forward_angles(int nAngles, float *angles);
+/* computeHybridPhaseFunctions (opticalProperties.f95:1937-2009) on [entry][angle] tables. */
+void orc_hybrid_phase_functions(int nAngles, int nEntries, const float *angles, const float *values,
+                                float gaussianWidthDeg, float *newValues);
+/* lookUpPhaseFuncValsFromTable (:1835-1870) for one angle. */
+float orc_lookup_phase_value(const float *table, int nAngles, float scatteringAngle);
+/* computeRT with intensity: intensity [nDir][ny][nx] raw sums; intensityByComponent
+ * [(nc+1)][nDir][ny][nx] and intensityExcess [(nc+1)][nDir] may be NULL unless
+ * limitContributions is set. */
+int64_t orc_compute_rt_intensity(const orc_problem *P, const orc_source *S, orc_rng *R,
+                                 int64_t numPhotons, float *fluxUp, float *fluxDown,
+                                 float *fluxAbsorbed, float *volumeAbsorption, orc_counters *C,
+                                 orc_fate *fates, const orc_intensity *I, float *intensity,
+                                 float *intensityByComponent, float *intensityExcess);
+/* computeRadiativeTransfer :294-320 (redistribution of excess) and :367-379 (normalisation). */
+void orc_normalize_intensity(const orc_problem *P, const orc_intensity *I, int64_t numPhotonsProcessed,
+                             float *intensity, float *intensityByComponent, const float *intensityExcess);
+
 /* ---- monteCarloRadiativeTransfer.f95 ------------------------------------ */
 /* computeRT (:393-841): raw tallies (zeroed here as :248-252 does). */
 int64_t orc_compute_rt(const orc_problem *P, const orc_source *S, orc_rng *R,

@@ -33,6 +33,16 @@ class OrcProblem(C.Structure):
     ]
 
 
+class OrcIntensity(C.Structure):
+    _fields_ = [
+        ("nDirections", C.c_int32), ("directions", C.c_void_p),
+        ("fwdTables", C.c_void_p), ("fwdOrigTables", C.c_void_p), ("fwdOffset", C.c_void_p), ("fwdNAngles", C.c_void_p),
+        ("useHybrid", C.c_int32), ("numOrdersOrig", C.c_int32),
+        ("useRussianRoulette", C.c_int32), ("zetaMin", C.c_float),
+        ("limitContributions", C.c_int32), ("maxContribution", C.c_float),
+    ]
+
+
 class OrcSource(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("solarMu", C.c_float), ("solarAzimuthDeg", C.c_float),
@@ -78,6 +88,15 @@ def lib():
         L.orc_random_real.restype = C.c_float
         L.orc_mt_next_u32.restype = C.c_uint32
         L.orc_accumulate_extinction.restype = C.c_float
+        L.orc_lookup_phase_value.restype = C.c_float
+        L.orc_compute_rt_intensity.restype = C.c_int64
+        L.orc_compute_rt_intensity.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 10
+        L.orc_normalize_intensity.argtypes = [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 3
+        L.orc_lookup_phase_value.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.orc_hybrid_phase_functions.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.orc_intensity_directions.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_forward_angles.argtypes = [C.c_int, C.c_void_p]
+        L.orc_phase_values_tabulated.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_compute_rt.restype = C.c_int64
         L.orc_compute_rt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 6
         L.orc_normalize.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 4
@@ -319,6 +338,101 @@ def compute_rt(problem, source, rng, n_photons, want_fates=False):
     if want_fates:
         res["fates"] = fates
     return res
+
+
+def intensity_directions(mus, phis_deg):
+    """makeDirectionCosines(mu, phi*Pi/180) per intensity direction -> [nDir, 3]."""
+    mus = np.ascontiguousarray(mus, np.float32)
+    phis = np.ascontiguousarray(phis_deg, np.float32)
+    out = np.zeros((mus.size, 3), np.float32)
+    lib().orc_intensity_directions(int(mus.size), _p(mus), _p(phis), _p(out))
+    return out
+
+
+def forward_angles(n):
+    a = np.zeros(int(n), np.float32)
+    lib().orc_forward_angles(int(n), _p(a))
+    return a
+
+
+def phase_values_tabulated(st_angles, st_values, angles):
+    sa = np.ascontiguousarray(st_angles, np.float32)
+    sv = np.ascontiguousarray(st_values, np.float32)
+    an = np.ascontiguousarray(angles, np.float32)
+    out = np.zeros(an.size, np.float32)
+    lib().orc_phase_values_tabulated(int(sa.size), _p(sa), _p(sv), int(an.size), _p(an), _p(out))
+    return out
+
+
+def hybrid_phase_functions(angles, values, width_deg):
+    """computeHybridPhaseFunctions on values[nEntries, nAngles]."""
+    an = np.ascontiguousarray(angles, np.float32)
+    v = np.ascontiguousarray(values, np.float32).reshape(-1, an.size)
+    out = np.zeros_like(v)
+    lib().orc_hybrid_phase_functions(int(an.size), int(v.shape[0]), _p(an), _p(v), float(width_deg), _p(out))
+    return out
+
+
+def lookup_phase_value(table, angle):
+    t = np.ascontiguousarray(table, np.float32)
+    return float(lib().orc_lookup_phase_value(_p(t), int(t.size), float(angle)))
+
+
+class Intensity:
+    """Owns the arrays behind an OrcIntensity: directions, forward tables, variance-reduction choices
+    (specifyParameters :1046-1292 + tabulateForwardPhaseFunctions)."""
+
+    def __init__(self, mus, phis_deg, fwd_tables, fwd_orig_tables=None, use_hybrid=False, num_orders_orig=0,
+                 use_russian_roulette=False, zeta_min=0.3, limit_contributions=False, max_contribution=3.4e38):
+        self.mus = np.ascontiguousarray(mus, np.float32)
+        self.phis = np.ascontiguousarray(phis_deg, np.float32)
+        self.dirs = intensity_directions(self.mus, self.phis)
+        self.nDir = int(self.mus.size)
+        self.fwd = [np.ascontiguousarray(t, np.float32).reshape(-1, np.asarray(t).shape[-1]) for t in fwd_tables]
+        orig = fwd_tables if fwd_orig_tables is None else fwd_orig_tables
+        self.orig = [np.ascontiguousarray(t, np.float32).reshape(-1, np.asarray(t).shape[-1]) for t in orig]
+        self.nAngles = np.array([t.shape[1] for t in self.fwd], np.int32)
+        self.offset = np.cumsum([0] + [t.size for t in self.fwd[:-1]]).astype(np.int64)
+        self.tab = np.concatenate([t.reshape(-1) for t in self.fwd]).astype(np.float32)
+        self.tabOrig = np.concatenate([t.reshape(-1) for t in self.orig]).astype(np.float32)
+        self.c = OrcIntensity(self.nDir, _p(self.dirs), _p(self.tab), _p(self.tabOrig), _p(self.offset), _p(self.nAngles),
+                              int(bool(use_hybrid)), int(num_orders_orig), int(bool(use_russian_roulette)),
+                              float(zeta_min), int(bool(limit_contributions)), float(max_contribution))
+
+
+def compute_rt_intensity(problem, source, rng, n_photons, inten):
+    """computeRT with radiance: raw sums incl. intensity[nDir, ny*nx] (+ byComponent, excess)."""
+    ncol = problem.nx * problem.ny
+    nvox = ncol * problem.nz
+    up, dn, ab = (np.zeros(ncol, np.float32) for _ in range(3))
+    vol = np.zeros(nvox, np.float32)
+    I = np.zeros((inten.nDir, ncol), np.float32)
+    byc = np.zeros((problem.nc + 1, inten.nDir, ncol), np.float32)
+    exc = np.zeros((problem.nc + 1, inten.nDir), np.float32)
+    cnt = OrcCounters()
+    src = source.c if hasattr(source, "c") else source
+    n = lib().orc_compute_rt_intensity(C.addressof(problem.c), C.addressof(src), C.addressof(rng), int(n_photons),
+                                       _p(up), _p(dn), _p(ab), _p(vol), C.addressof(cnt), None,
+                                       C.addressof(inten.c), _p(I), _p(byc), _p(exc))
+    return {"n": int(n), "fluxUp": up, "fluxDown": dn, "fluxAbsorbed": ab, "volumeAbsorption": vol,
+            "intensity": I, "intensityByComponent": byc, "intensityExcess": exc, "counters": cnt.as_dict()}
+
+
+def compute_radiative_transfer_intensity(problem, source, rng, n_photons, inten):
+    """computeRadiativeTransfer + reportResults with radiance: normalised per-batch results;
+    intensity[nDir, ny*nx], meanIntensity[nDir] (:980-992)."""
+    raw = compute_rt_intensity(problem, source, rng, n_photons, inten)
+    norm = normalize(problem, raw["n"], raw)
+    I = raw["intensity"].copy()
+    byc = raw["intensityByComponent"].copy()
+    lib().orc_normalize_intensity(C.addressof(problem.c), C.addressof(inten.c), int(raw["n"]), _p(I), _p(byc),
+                                  _p(raw["intensityExcess"]))
+    mu, md, ma, prof = report_means(problem, norm)
+    ncol = problem.nx * problem.ny
+    mean_i = np.array([np.sum(I[d], dtype=np.float32) / np.float32(ncol) for d in range(inten.nDir)], np.float32)
+    norm.update(meanFluxUp=mu, meanFluxDown=md, meanFluxAbsorbed=ma, absorbedProfile=prof, n=raw["n"],
+                counters=raw["counters"], intensity=I, intensityByComponent=byc, meanIntensity=mean_i)
+    return norm
 
 
 def normalize(problem, n_done, res):

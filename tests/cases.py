@@ -125,6 +125,24 @@ def oracle_problem(case, nsteps=10001, use_russian_roulette=True, lw_flag=-1.0):
                      use_russian_roulette=use_russian_roulette, lw_flag=lw_flag)
 
 
+def oracle_intensity(case, mus, phis_deg, n_angles=9001, hybrid_width=None, **kw):
+    """Intensity set-up for the ORACLE (tests only): forward tables of every component at n_angles equally spaced
+    angles (tabulateForwardPhaseFunctions), hybrid versions when hybrid_width (degrees) is given."""
+    from oracle import oracle as O
+    angles = O.forward_angles(n_angles)
+    orig = []
+    for comp in case["components"]:
+        if "tabulated" in comp:
+            orig.append(np.stack([O.phase_values_tabulated(a, O.normalize_phase_function(a, v), angles)
+                                  for a, v in comp["tabulated"]]))
+        else:
+            orig.append(np.stack([O.phase_values_legendre(c, angles) for c in comp["legendre"]]))
+    if hybrid_width:
+        tabs = [O.hybrid_phase_functions(angles, t, hybrid_width) for t in orig]
+        return O.Intensity(mus, phis_deg, tabs, orig, use_hybrid=True, **kw)
+    return O.Intensity(mus, phis_deg, orig, None, **kw)
+
+
 def product_domain(case):
     """Hand a case to the PRODUCT through its reference-shaped host interface."""
     import mcbrat3d_amd as M
