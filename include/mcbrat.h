@@ -27,6 +27,7 @@ extern "C" {
 #endif
 
 #define MCBRAT_MAX_COMPONENTS 8
+#define MCBRAT_MAX_DIRECTIONS 64 /* intensity directions per run */
 #define MCBRAT_ABI_VERSION 1
 
 typedef struct mcbrat_ctx mcbrat_ctx;
@@ -105,13 +106,40 @@ int mcbrat_report_results(mcbrat_ctx *ctx, float *meanFluxUp, float *meanFluxDow
                           float *meanFluxAbsorbed, float *fluxUp, float *fluxDown,
                           float *fluxAbsorbed, float *absorbedProfile, float *volumeAbsorption);
 
+/* ---- radiance by local estimation (computeIntensityContribution :1623-1832) ---------------
+ * specifyParameters(intensityMus, intensityPhis, computeIntensity, useRussianRouletteForIntensity,
+ * zetaMin, useHybridPhaseFunsForIntenCalcs, numOrdersOrigPhaseFunIntenCalcs,
+ * limitIntensityContributions, maxIntensityContribution) (:1046-1292).  nDirections = 0 turns the
+ * intensity calculation off.  mus in [-1, 1] \ {0}, phis in degrees [0, 360].  Every emitted-photon
+ * launch, surface reflection and scattering event then adds weight * phase function /
+ * (4 pi |mu|) * transmission to the pixel where the view ray leaves the domain.
+ * Roulette (Iwabuchi 2006, the driver's default) is accepted for upward directions only: for
+ * mu < 0 the reference restarts its walk below the surface.  limitIntensityContributions (off by
+ * default) is not supported.  Changing the number of directions changes mcbrat_moments_length():
+ * a caller-bound moment buffer must be bound again. */
+int mcbrat_specify_intensity(mcbrat_ctx *ctx, int32_t nDirections, const float *intensityMus,
+                             const float *intensityPhisDeg, int32_t useRussianRouletteForIntensity,
+                             float zetaMin, int32_t useHybridPhaseFunsForIntenCalcs,
+                             int32_t numOrdersOrigPhaseFunIntenCalcs,
+                             int32_t limitIntensityContributions, float maxIntensityContribution);
+/* tabulatedPhaseFunctions(component)%values(nAngles, nEntries) and tabulatedOrigPhaseFunctions
+ * (tabulateForwardPhaseFunctions, opticalProperties.f95:1872-1935; pulled by
+ * computeIntensityContribution :1672): phase function values at nAngles scattering angles equally
+ * spaced on [0, pi], angle fastest.  origTable = NULL when no hybrid tables are used. */
+int mcbrat_set_forward_table(mcbrat_ctx *ctx, int32_t component, int32_t nAngles, int32_t nEntries,
+                             const float *table, const float *origTable);
+/* reportResults(meanIntensity, intensity) (:980-1010) for the LAST batch: intensity is
+ * [nDirections][ny][nx] (x fastest).  Either pointer may be NULL. */
+int mcbrat_report_intensity(mcbrat_ctx *ctx, float *meanIntensity, float *intensity);
+
 /* Batch moments: what the driver keeps in *Stats(...,1:2)
  * (monteCarloDriver.f95:603-616) and reduces with sumAcrossProcesses
  * (:1151-1166).  One double array:
  *   [0] total photons  [1] batches completed  [2..7] reserved
  *   then S1 = sum n*x and S2 = sum n*x^2, each of length mcbrat_moments_length():
  *   meanFluxUp, meanFluxDown, meanFluxAbsorbed, fluxUp[nx*ny], fluxDown[nx*ny],
- *   fluxAbsorbed[nx*ny], absorbedProfile[nz], absorbedVolume[nx*ny*nz].
+ *   fluxAbsorbed[nx*ny], absorbedProfile[nz], absorbedVolume[nx*ny*nz],
+ *   intensity[nDirections*nx*ny] (RadianceStats, monteCarloDriver.f95:1047-1050).
  * Total doubles = 8 + 2*length.  The buffer is device memory; a caller that
  * wants to all-reduce it with RCCL binds its own device buffer. */
 int64_t mcbrat_moments_length(const mcbrat_ctx *ctx);
@@ -167,6 +195,16 @@ int mcbrat_inverse_table_legendre(int32_t nCoefficients, const float *coefficien
  * normalised as new_PhaseFunction does (scatteringPhaseFunctions.f95:156). */
 int mcbrat_inverse_table_tabulated(int32_t nAngles, const float *scatteringAngle,
                                    const float *value, int32_t nSteps, float *table);
+/* tabulateForwardPhaseFunctions for one phase function (opticalProperties.f95:1914-1916 ->
+ * getPhaseFunctionValues, scatteringPhaseFunctions.f95:480-527): values at nAngles angles equally
+ * spaced on [0, pi], from Legendre coefficients or from (angle, value) pairs. */
+int mcbrat_forward_table_legendre(int32_t nCoefficients, const float *coefficients, int32_t nAngles,
+                                  float *table);
+int mcbrat_forward_table_tabulated(int32_t nStored, const float *scatteringAngle, const float *value,
+                                   int32_t nAngles, float *table);
+/* computeHybridPhaseFunctions (opticalProperties.f95:1937-2009) on values[nEntries][nAngles]. */
+int mcbrat_hybrid_phase_functions(int32_t nAngles, int32_t nEntries, const float *values,
+                                  float gaussianWidthDeg, float *hybridValues);
 /* emission_weighting (src/emissionAndBroadBandWeights.f95:424-550): builds
  * voxelWeights (running CDF, x fastest), fracAtmsPower and the emitted flux. */
 int mcbrat_emission_weighting(int32_t nx, int32_t ny, int32_t nz, int32_t nComponents,

@@ -56,6 +56,12 @@ SYMBOLS = {
     "mcbrat_enable_counters": (C.c_int, [_vp, _i32]),
     "mcbrat_get_counters": (C.c_int, [_vp, _vp]),
     "mcbrat_last_trace_ms": (_f, [_vp]),
+    "mcbrat_specify_intensity": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _f, _i32, _i32, _i32, _f]),
+    "mcbrat_set_forward_table": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "mcbrat_report_intensity": (C.c_int, [_vp, _vp, _vp]),
+    "mcbrat_forward_table_legendre": (C.c_int, [_i32, _vp, _i32, _vp]),
+    "mcbrat_forward_table_tabulated": (C.c_int, [_i32, _vp, _vp, _i32, _vp]),
+    "mcbrat_hybrid_phase_functions": (C.c_int, [_i32, _i32, _vp, _f, _vp]),
     "mcbrat_set_async": (C.c_int, [_vp, _i32]),
     "mcbrat_synchronize": (C.c_int, [_vp]),
     "mcbrat_stream_wait_done": (C.c_int, [_vp, _vp]),

@@ -72,6 +72,16 @@ struct mcbrat_ctx {
   bool tablesDirty = true;
   int tblTotalFloats = 0;
   int tblOffset[MCBRAT_MAX_COMPONENTS] = {0};
+  // radiance by local estimation
+  int nDir = 0;
+  std::vector<float> dirData;  // [nDir][8], see DevParams
+  float *dDirData = nullptr, *dFwd = nullptr, *dFwdOrig = nullptr;
+  std::vector<std::vector<float>> fwd, fwdOrig;  // per component [nEntries][nAngles]
+  std::vector<int> fwdNAngles, fwdNEntries;
+  int fwdOffset[MCBRAT_MAX_COMPONENTS] = {0};
+  bool fwdDirty = true;
+  int useHybrid = 0, numOrdersOrig = 0, useRRIntensity = 0;
+  float zetaMin = 0.3f;
   // parameters
   float albedo = 0.f;
   int useRR = 1;
@@ -163,7 +173,7 @@ int upload(mcbrat_ctx *c, T **dst, const T *src, size_t n) {
 
 long long moments_len(const mcbrat_ctx *c) {
   const long long ncol = (long long)c->nx * c->ny;
-  return 3 + 3 * ncol + c->nz + ncol * c->nz;
+  return 3 + 3 * ncol + c->nz + ncol * c->nz + (long long)c->nDir * ncol;
 }
 
 int ensure_moments(mcbrat_ctx *c) {
@@ -190,6 +200,26 @@ int sync_tables(mcbrat_ctx *c) {
   c->tblTotalFloats = (int)all.size();
   if (upload(c, &c->dTables, all.data(), all.size())) return 1;
   c->tablesDirty = false;
+  return 0;
+}
+
+// forward tables for radiance, uploaded before the first launch that needs them
+int sync_forward_tables(mcbrat_ctx *c) {
+  if (c->nDir == 0 || !c->fwdDirty) return 0;
+  if (sync_all(c)) return 1;
+  std::vector<float> all, allOrig;
+  for (int k = 0; k < c->nc; ++k) {
+    if ((int)c->fwd.size() <= k || c->fwd[k].empty())
+      return fail(c, "tabulateForwardPhaseFunctions: no forward phase function table for component " + std::to_string(k + 1));
+    if (c->maxPfi[k] >= c->fwdNEntries[k])
+      return fail(c, "tabulateForwardPhaseFunctions: phaseFunctionIndex exceeds table entries for component " + std::to_string(k + 1));
+    c->fwdOffset[k] = (int)all.size();
+    all.insert(all.end(), c->fwd[k].begin(), c->fwd[k].end());
+    allOrig.insert(allOrig.end(), c->fwdOrig[k].begin(), c->fwdOrig[k].end());
+  }
+  if (upload(c, &c->dFwd, all.data(), all.size()) || upload(c, &c->dFwdOrig, allOrig.data(), allOrig.size())) return 1;
+  if (upload(c, &c->dDirData, c->dirData.data(), c->dirData.size())) return 1;
+  c->fwdDirty = false;
   return 0;
 }
 
@@ -284,7 +314,7 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
 // dense grid is as fast or 1-3 % faster, so the automatic rule only switches
 // for grids of 64 MiB and more.
 bool use_bricks(const mcbrat_ctx *c) {
-  if (!c->bricksBuilt || c->brickMode == 0) return false;
+  if (!c->bricksBuilt || c->brickMode == 0 || c->nDir > 0) return false;  // (radiance rays read the dense grid)
   if (c->brickMode == 1) return true;
   const size_t nvox = (size_t)c->nx * c->ny * c->nz;
   return nvox * sizeof(float) >= ((size_t)64 << 20) && c->backgroundFraction >= 0.5;
@@ -319,6 +349,10 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.dir0[0] = c->dir0[0]; p.dir0[1] = c->dir0[1]; p.dir0[2] = c->dir0[2];
   p.zLaunch = c->zLaunch; p.izLaunch = c->izLaunch;
   p.voxelCDF = c->dVoxelCDF; p.fracAtms = c->fracAtms;
+  p.nDir = c->nDir;
+  p.dirData = c->dDirData; p.fwdTables = c->dFwd; p.fwdOrig = c->dFwdOrig;
+  for (int k = 0; k < c->nc && c->nDir > 0; ++k) { p.fwdOffset[k] = c->fwdOffset[k]; p.fwdNAngles[k] = c->fwdNAngles[k]; }
+  p.useHybrid = c->useHybrid; p.numOrdersOrig = c->numOrdersOrig; p.useRRIntensity = c->useRRIntensity; p.zetaMin = c->zetaMin;
   p.counter = c->L().dCounter;
   p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
   p.launchThreshold = std::max(1, std::min(64, c->launchThreshold));
@@ -359,11 +393,11 @@ size_t plan_launch_lds(const mcbrat_ctx *c, const LaunchPlan &L) {
          (L.tblLds ? sizeof(float) * (size_t)c->tblTotalFloats : 0);
 }
 
-template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG>
+template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN = false>
 int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   int perCU = c->blocksPerCU;
   if (perCU <= 0) {
-    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG>, BLOCK, lds));
+    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN>, BLOCK, lds));
     perCU = std::max(1, std::min(perCU, 8));
   }
   unsigned long long blocks = (unsigned long long)perCU * c->numCUs;
@@ -379,13 +413,23 @@ int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
     blocks = std::min(blocks, (p.total + BLOCK - 1) / BLOCK);
   }
   const unsigned grid = (unsigned)std::max<unsigned long long>(1, blocks);
-  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG>), dim3(grid), dim3(BLOCK), lds, c->L().stream, p);
+  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN>), dim3(grid), dim3(BLOCK), lds, c->L().stream, p);
   HIP_OK(c, hipGetLastError());
   return 0;
 }
 
 template <int BLOCK, bool DBG>
 int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatches) {
+  // radiance runs: dense grids, no instrumentation
+  if (c->nDir > 0) {
+    if (DBG) return fail(c, "computeRadiativeTransfer: event counters / photon fates are not available together with intensity directions.");
+    if (L.priv && L.gridLds) return L.tblLds ? launch_trace_t<BLOCK, true, 2, false, false, true>(c, p, L.lds, nBatches)
+                                             : launch_trace_t<BLOCK, false, 2, false, false, true>(c, p, L.lds, nBatches);
+    if (L.priv) return L.tblLds ? launch_trace_t<BLOCK, true, 1, false, false, true>(c, p, L.lds, nBatches)
+                                : launch_trace_t<BLOCK, false, 1, false, false, true>(c, p, L.lds, nBatches);
+    return L.tblLds ? launch_trace_t<BLOCK, true, 0, false, false, true>(c, p, L.lds, nBatches)
+                    : launch_trace_t<BLOCK, false, 0, false, false, true>(c, p, L.lds, nBatches);
+  }
   // instantiated combinations: private tallies (small domains) and bricks (large ones) never coincide
   if (L.priv && L.gridLds) return L.tblLds ? launch_trace_t<BLOCK, true, 2, false, DBG>(c, p, L.lds, nBatches)
                                            : launch_trace_t<BLOCK, false, 2, false, DBG>(c, p, L.lds, nBatches);
@@ -412,7 +456,8 @@ int check_ready(mcbrat_ctx *c) {
   if (!c) return 1;
   if (!c->haveGrid || !c->haveOptics) return fail(c, "computeRadiativeTransfer: problem not completely specified.");
   if (!c->haveSource) return fail(c, "computeRadiativeTransfer: no photon source set.");
-  return sync_tables(c);
+  if (sync_tables(c)) return 1;
+  return sync_forward_tables(c);
 }
 
 
@@ -693,6 +738,92 @@ int mcbrat_get_counters(mcbrat_ctx *c, mcbrat_counters *out) {
 }
 float mcbrat_last_trace_ms(const mcbrat_ctx *c) { return c ? c->lastTraceMs : 0.f; }
 
+int mcbrat_set_forward_table(mcbrat_ctx *c, int32_t component, int32_t nAngles, int32_t nEntries, const float *table,
+                             const float *origTable) {
+  if (!c) return 1;
+  if (!c->haveOptics) return fail(c, "tabulateForwardPhaseFunctions: domain has no optical components yet.");
+  if (component < 1 || component > c->nc) return fail(c, "tabulatePhaseFunctions: failed on component" + std::to_string(component));
+  if (nAngles < 2 || nEntries < 1 || !table) return fail(c, "tabulateForwardPhaseFunctions: table has the wrong number of entries");
+  c->fwd.resize(c->nc); c->fwdOrig.resize(c->nc); c->fwdNAngles.resize(c->nc, 0); c->fwdNEntries.resize(c->nc, 0);
+  c->fwd[component - 1].assign(table, table + (size_t)nAngles * nEntries);
+  const float *o = origTable ? origTable : table;
+  c->fwdOrig[component - 1].assign(o, o + (size_t)nAngles * nEntries);
+  c->fwdNAngles[component - 1] = nAngles;
+  c->fwdNEntries[component - 1] = nEntries;
+  c->fwdDirty = true;
+  return 0;
+}
+
+int mcbrat_specify_intensity(mcbrat_ctx *c, int32_t nDirections, const float *mus, const float *phisDeg,
+                             int32_t useRussianRouletteForIntensity, float zetaMin,
+                             int32_t useHybridPhaseFunsForIntenCalcs, int32_t numOrdersOrigPhaseFunIntenCalcs,
+                             int32_t limitIntensityContributions, float maxIntensityContribution) {
+  if (!c) return 1;
+  if (!c->haveGrid) return fail(c, "specifyParameters: set the grid first.");
+  if (nDirections < 0 || nDirections > MCBRAT_MAX_DIRECTIONS || (nDirections > 0 && (!mus || !phisDeg)))
+    return fail(c, "specifyParameters: invalid number of intensity directions.");
+  for (int i = 0; i < nDirections; ++i) {  // specifyParameters :1140-1145
+    if (mus[i] < -1.f || mus[i] > 1.f) return fail(c, "specifyParameters: intensityMus must be between -1 and 1");
+    if (std::fabs(mus[i]) < FLT_MIN) return fail(c, "specifyParameters: intensityMus can't be 0 (directly sideways)");
+    if (phisDeg[i] < 0.f || phisDeg[i] > 360.f) return fail(c, "specifyParameters: intensityPhis must be between 0 and 360");
+  }
+  if (limitIntensityContributions && maxIntensityContribution < FLT_MAX)
+    return fail(c, "specifyParameters: limitIntensityContributions is not supported (off by default in the reference's driver).");
+  if (zetaMin < 0.f) return fail(c, "specifyParameters: zetaMin must be >= 0.");
+  if (numOrdersOrigPhaseFunIntenCalcs < 0) return fail(c, "specifyParameters: numOrdersOrigPhaseFunIntenCalcs must be >= 0");
+  if (useRussianRouletteForIntensity)
+    for (int i = 0; i < nDirections; ++i)
+      if (mus[i] < 0.f)
+        return fail(c, "specifyParameters: useRussianRouletteForIntensity only works for upward directions "
+                       "(the reference restarts the walk below the surface for mu < 0).");
+  (void)hipSetDevice(c->device);
+  if (sync_all(c)) return 1;
+  constexpr float kPi = 3.14159265358979312f;
+  c->dirData.assign((size_t)8 * std::max(nDirections, 1), 0.f);
+  for (int i = 0; i < nDirections; ++i) {  // makeDirectionCosines(mu, phi * Pi/180) :1270-1272, :1876-1894
+    const float mu = mus[i], phi = phisDeg[i] * kPi / 180.0f;
+    const float sinTheta = std::sqrt(1.0f - mu * mu);
+    float *d = &c->dirData[(size_t)8 * i];
+    d[0] = sinTheta * std::cos(phi); d[1] = sinTheta * std::sin(phi); d[2] = mu;
+    d[3] = (4.0f * kPi) * std::fabs(d[2]);
+    for (int a = 0; a < 3; ++a) d[4 + a] = std::fabs(d[a]) >= 2.0f * FLT_MIN ? 1.0f / d[a] : 0.0f;
+  }
+  if (nDirections != c->nDir) {  // the moment arrays change length: start them afresh
+    if (c->dMomentsOwned) { (void)hipFree(c->dMomentsOwned); c->dMomentsOwned = nullptr; }
+    c->dMoments = nullptr;
+    if (c->dLast) { (void)hipFree(c->dLast); c->dLast = nullptr; }
+    for (mcbrat_ctx::Lane &L : c->lane) L.slabCapacity = L.finishCapacity = 0;
+    c->haveLast = false;
+    c->tuned = false;
+  }
+  c->nDir = nDirections;
+  c->useRRIntensity = useRussianRouletteForIntensity ? 1 : 0;
+  c->zetaMin = zetaMin;
+  c->useHybrid = useHybridPhaseFunsForIntenCalcs ? 1 : 0;
+  c->numOrdersOrig = numOrdersOrigPhaseFunIntenCalcs;
+  c->fwdDirty = true;
+  return 0;
+}
+
+int mcbrat_report_intensity(mcbrat_ctx *c, float *meanIntensity, float *intensity) {
+  if (!c) return 1;
+  if (c->nDir == 0) return fail(c, "reportResults: intensity information not available");
+  if (!c->haveLast) return fail(c, "reportResults: no batch has been traced yet.");
+  (void)hipSetDevice(c->device);
+  if (sync_all(c)) return 1;
+  const size_t ncol = (size_t)c->nx * c->ny, base = 3 + 3 * ncol + c->nz + ncol * c->nz;
+  std::vector<float> h(ncol * c->nDir);
+  HIP_OK(c, hipMemcpy(h.data(), c->dLast + base, sizeof(float) * h.size(), hipMemcpyDeviceToHost));
+  if (intensity) std::memcpy(intensity, h.data(), sizeof(float) * h.size());
+  if (meanIntensity)
+    for (int d = 0; d < c->nDir; ++d) {  // reportResults :980-992
+      float s = 0.f;
+      for (size_t i = 0; i < ncol; ++i) s += h[(size_t)d * ncol + i];
+      meanIntensity[d] = s / (float)ncol;
+    }
+  return 0;
+}
+
 int mcbrat_set_async(mcbrat_ctx *c, int32_t enable) {
   if (!c) return 1;
   (void)hipSetDevice(c->device);
@@ -760,7 +891,7 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     c->cur = 0;
   }
   const size_t ncol = (size_t)c->nx * c->ny, nvox = ncol * c->nz;
-  const size_t slabStride = 2 * ncol + nvox;
+  const size_t slabStride = 2 * ncol + nvox + (size_t)c->nDir * ncol;  // [fluxUp | fluxDown | volume | intensity per direction]
   // batches in flight: bounded by a memory budget (slabs are 8 B per tally bin per batch)
   size_t inFlight = std::max<size_t>(1, (size_t)(4ull << 30) / (slabStride * sizeof(long long)));
   if (c->maxBatchesInFlight > 0) inFlight = std::min<size_t>(inFlight, (size_t)c->maxBatchesInFlight);
@@ -821,13 +952,15 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     if (c->lastDone && c->lastDone != c->L().evDone) HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->lastDone, 0));
     if (c->externalPending) { HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->evExternal, 0)); c->externalPending = false; }
     FinishParams f;
-    f.nx = c->nx; f.ny = c->ny; f.nz = c->nz; f.nBatches = nb; f.xyRegular = c->xyRegular;
+    f.nx = c->nx; f.ny = c->ny; f.nz = c->nz; f.nBatches = nb; f.xyRegular = c->xyRegular; f.nDir = c->nDir;
     f.ppb = p.ppb; f.total = p.total; f.slabStride = slabStride;
     f.slabs = c->L().dSlabs; f.relArea = c->dRelArea; f.ze = c->dEdges + (c->nx + 1) + (c->ny + 1);
     f.colVals = c->L().dColVals; f.scalVals = c->L().dScalVals; f.moments = c->dMoments; f.last = c->dLast;
     hipLaunchKernelGGL(finish_columns, dim3((unsigned)((ncol * (size_t)nb + 255) / 256)), dim3(256), 0, c->L().stream, f);
     hipLaunchKernelGGL(finish_column_moments, dim3((unsigned)((3 * ncol + 255) / 256)), dim3(256), 0, c->L().stream, f);
     hipLaunchKernelGGL(finish_volume, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, c->L().stream, f);
+    if (c->nDir > 0)
+      hipLaunchKernelGGL(finish_intensity, dim3((unsigned)((ncol * (size_t)c->nDir + 255) / 256)), dim3(256), 0, c->L().stream, f);
     hipLaunchKernelGGL(finish_reduce, dim3(3 + c->nz, nb), dim3(256), 0, c->L().stream, f);
     hipLaunchKernelGGL(finish_scalars, dim3((unsigned)((3 + c->nz + 255) / 256)), dim3(256), 0, c->L().stream, f);
     HIP_OK(c, hipGetLastError());
@@ -890,6 +1023,7 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
   if (check_ready(c)) return 1;
   if (n < 1 || !fates) return fail(c, "trace_fates: nothing to trace.");
   if (sync_all(c)) return 1;
+  if (c->nDir > 0) return fail(c, "trace_fates: not available together with intensity directions.");
   const size_t ncol = (size_t)c->nx * c->ny, nvox = ncol * c->nz;
   const size_t slabStride = 2 * ncol + nvox;
   long long *scratch = nullptr;

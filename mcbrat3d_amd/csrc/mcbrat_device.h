@@ -51,6 +51,16 @@ struct DevParams {
   int izLaunch;                   // directional: 0-based launch layer
   const double *voxelCDF;         // emission: running CDF [nvox]
   double fracAtms;
+  // radiance by local estimation (computeIntensityContribution :1623-1832); nDir == 0: fluxes only
+  int nDir;
+  const float *dirData;           // [nDir][8]: direction cosines, 4 pi |mu|, 1/dx, 1/dy, 1/dz (0 where |d| is tiny), pad
+  const float *fwdTables;         // tabulatedPhaseFunctions: components concatenated, [entry][angle]
+  const float *fwdOrig;           // tabulatedOrigPhaseFunctions (hybrid runs), same layout
+  int fwdOffset[MCBRAT_MAX_COMPONENTS];
+  int fwdNAngles[MCBRAT_MAX_COMPONENTS];
+  int useHybrid, numOrdersOrig;   // original tables up to this scattering order, hybrid ones beyond
+  int useRRIntensity;             // Iwabuchi (2006) roulette on the local estimates
+  float zetaMin;
   // work
   unsigned long long *counter;    // next global photon index
   unsigned long long total;       // photons in this launch

@@ -179,6 +179,107 @@ extern "C" int mcbrat_inverse_table_tabulated(int32_t nAngles, const float *angl
   return 0;
 }
 
+// ---- forward phase-function tables for radiance (tabulateForwardPhaseFunctions,
+// src/opticalProperties.f95:1872-1935): values at nAngles equally spaced scattering angles ----
+namespace {
+constexpr float kPiF = 3.14159265358979312f;
+
+std::vector<float> forward_angles(int nAngles) {  // :1914
+  std::vector<float> a(nAngles);
+  for (int j = 0; j < nAngles; ++j) a[j] = ((float)j / (float)(nAngles - 1)) * kPiF;
+  return a;
+}
+
+// computeNormalization (:2026-2050) and phaseFuncDiff (:2011-2024); t is the 1-based transition index
+float hybrid_norm(const std::vector<float> &cosA, const float *v, const std::vector<float> &g, int t) {
+  const int n = (int)cosA.size();
+  float ig = 0.0f, io = 0.0f;
+  for (int k = 1; k <= t - 1; ++k) ig += (0.5f * (g[k - 1] + g[k])) * (cosA[k - 1] - cosA[k]);
+  for (int k = t; k <= n - 1; ++k) io += (0.5f * (v[k - 1] + v[k])) * (cosA[k - 1] - cosA[k]);
+  return io >= 2.0f ? 1.0f / ig : (2.0f - io) / ig;
+}
+float hybrid_diff(const std::vector<float> &cosA, const float *v, const std::vector<float> &g, int t) {
+  return hybrid_norm(cosA, v, g, t) * g[t - 1] - v[t - 1];
+}
+}  // namespace
+
+extern "C" int mcbrat_forward_table_legendre(int32_t nCoef, const float *coef, int32_t nAngles, float *table) {
+  if (nCoef < 0 || nAngles < 2 || !table || (nCoef > 0 && !coef)) return 1;
+  if (nCoef == 0) {  // isotropic: P0 only (scatteringPhaseFunctions.f95:486-491)
+    for (int j = 0; j < nAngles; ++j) table[j] = 0.5f;
+    return 0;
+  }
+  const std::vector<float> ang = forward_angles(nAngles);
+  std::vector<float> c(nAngles), P;
+  for (int j = 0; j < nAngles; ++j) c[j] = std::cos(ang[j]);
+  legendre_polynomials(nCoef, c, P);
+  for (int j = 0; j < nAngles; ++j) {  // :493-496
+    float s = 0.0f;
+    for (int l = 0; l <= nCoef; ++l) s += ((l == 0 ? 1.0f : coef[l - 1]) * (float)(2 * l + 1)) * P[(size_t)j * (nCoef + 1) + l];
+    table[j] = s;
+  }
+  return 0;
+}
+
+extern "C" int mcbrat_forward_table_tabulated(int32_t nStored, const float *angle, const float *value, int32_t nAngles,
+                                              float *table) {
+  if (nStored < 2 || nAngles < 2 || !angle || !value || !table) return 1;
+  float dot = 0.0f;  // normalizePhaseFunction, scatteringPhaseFunctions.f95:1520-1536
+  for (int i = 0; i < nStored - 1; ++i) dot += (std::cos(angle[i + 1]) - std::cos(angle[i])) * (0.5f * (value[i + 1] + value[i]));
+  std::vector<float> stored(nStored), st(angle, angle + nStored);
+  for (int i = 0; i < nStored; ++i) stored[i] = (-value[i] * 2.0f) / dot;
+  const std::vector<float> ang = forward_angles(nAngles);
+  for (int l = 0; l < nAngles; ++l) {  // interpolation in the cosine of the angle, :500-527
+    const int ti = std::max(1, find_index(ang[l], st, 0));
+    int tp = ti + 1;
+    float dMu;
+    if (ti < nStored) dMu = std::cos(st[tp - 1]) - std::cos(st[ti - 1]);
+    else { dMu = FLT_MAX; tp = ti; }
+    const float wt = 1.0f - (std::cos(ang[l]) - std::cos(st[ti - 1])) / dMu;
+    table[l] = wt * stored[ti - 1] + (1.0f - wt) * stored[tp - 1];
+  }
+  return 0;
+}
+
+// computeHybridPhaseFunctions (:1937-2009): the forward peak of each entry is replaced by a Gaussian of the given
+// width, continuous with the original at the transition angle and normalised together with it.
+extern "C" int mcbrat_hybrid_phase_functions(int32_t nAngles, int32_t nEntries, const float *values, float widthDeg,
+                                             float *out) {
+  if (nAngles < 4 || nEntries < 1 || !values || !out || !(widthDeg > 0.0f)) return 1;
+  const std::vector<float> ang = forward_angles(nAngles);
+  std::vector<float> g(nAngles), cosA(nAngles);
+  for (int k = 0; k < nAngles; ++k) {
+    cosA[k] = std::cos(ang[k]);
+    const float x = ang[k] / (widthDeg * kPiF / 180.0f);
+    g[k] = std::exp(-(x * x));
+  }
+  std::memcpy(out, values, sizeof(float) * (size_t)nAngles * nEntries);
+  for (int e = 0; e < nEntries; ++e) {
+    const float *v = values + (size_t)e * nAngles;
+    int lo = find_index(widthDeg * kPiF / 180.0f, ang, 0) + 1;
+    if (lo >= nAngles - 2) break;
+    float dLo = hybrid_diff(cosA, v, g, lo), dUp = 0.0f;
+    int inc = 1, up = lo;
+    bool root = true;
+    for (;;) {  // hunt for a sign change
+      up = std::min(lo + inc, nAngles - 1);
+      dUp = hybrid_diff(cosA, v, g, up);
+      if (lo == nAngles - 1) { root = false; break; }
+      if (dLo * dUp < 0.0f) break;
+      lo = up; dLo = dUp; inc *= 2;
+    }
+    if (!root) continue;  // no transition angle: the original phase function stays
+    while (up > lo + 1) {  // bisection
+      const int mid = (lo + up) / 2;
+      const float dMid = hybrid_diff(cosA, v, g, mid);
+      if (dMid * dUp < 0.0f) { lo = mid; dLo = dMid; } else { up = mid; dUp = dMid; }
+    }
+    const float P0 = hybrid_norm(cosA, v, g, lo);
+    for (int k = 0; k < lo; ++k) out[(size_t)e * nAngles + k] = P0 * g[k];
+  }
+  return 0;
+}
+
 // emission_weightingNEW, src/emissionAndBroadBandWeights.f95:424-550.
 extern "C" int mcbrat_emission_weighting(int32_t nx, int32_t ny, int32_t nz, int32_t nc, const double *xe,
                                          const double *ye, const double *ze, const double *temps,

@@ -175,7 +175,9 @@ __device__ __forceinline__ float load_ext(const DevParams &p, const float *s_bgE
 }
 
 // PRIV: 0 tallies by global atomics, 1 LDS-private tally slab, 2 private slab and the optical grid in LDS too
-template <int BLOCK, bool TBL_LDS, int PRIV, bool BRICK, bool DEBUG>
+// INTEN: radiance by local estimation (computeIntensityContribution :1623-1832): every launch of an emitted
+// photon, surface reflection and scattering event sends a contribution along each view direction.
+template <int BLOCK, bool TBL_LDS, int PRIV, bool BRICK, bool DEBUG, bool INTEN = false>
 __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel(const DevParams p) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   // LDS map: [edges x|y|z (double)] [private tally slab (i64), PRIV] [unit cursor, PRIV]
@@ -200,6 +202,11 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
   // kernel-argument segment (a vector load from there costs a trip to memory on every collision)
   __shared__ int s_tblOffset[MCBRAT_MAX_COMPONENTS], s_tblNSteps[MCBRAT_MAX_COMPONENTS];
   __shared__ float s_tblInvN[MCBRAT_MAX_COMPONENTS];
+  __shared__ int s_fwdOffset[MCBRAT_MAX_COMPONENTS], s_fwdNAngles[MCBRAT_MAX_COMPONENTS];
+  if (INTEN && threadIdx.x < MCBRAT_MAX_COMPONENTS) {
+    s_fwdOffset[threadIdx.x] = p.fwdOffset[threadIdx.x];
+    s_fwdNAngles[threadIdx.x] = p.fwdNAngles[threadIdx.x];
+  }
   if (threadIdx.x < MCBRAT_MAX_COMPONENTS) {
     s_tblOffset[threadIdx.x] = p.tblOffset[threadIdx.x];
     s_tblNSteps[threadIdx.x] = p.tblNSteps[threadIdx.x];
@@ -242,6 +249,11 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
   int ex = 0, ey = 0, ez = 0;  // index in the LDS edge table of the next x / y / z face of the leg
   int cell = 0;                // linear index of the current cell
   int nScat = 0, nLegs = 0;
+  // INTEN: a pending local estimate of this lane: 0 none, 1 Lambertian surface (component 0 of the reference),
+  // 2 isotropic emission (component -1), 3 + c scattering by component c; its weight, incoming direction and
+  // the offset of the phase-function entry in the forward tables
+  int iFlag = 0, iEntry = 0;
+  float iW = 0, iDx = 0, iDy = 0, iDz = 0;
   unsigned long long chunkNext = 0, chunkEnd = 0;  // global mode, wave-uniform
   unsigned int cLegs = 0, cCross = 0, cColl = 0, cAbs = 0, cTop = 0, cSurf = 0, cKill = 0, cSurv = 0;
   // DEBUG, wave level (lane 0): loop iterations and how many lanes each kind of phase served
@@ -399,6 +411,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
               if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + cell), to_fixed(-1.0));
               else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + 2 * ncol + cell), to_fixed(-1.0));
             }
+            if (INTEN && p.lwFlag) { iFlag = pz == 0.0 ? 1 : 2; iW = w; }  // :510-541 emission seen directly
             needLeg = true;
           } else {
             more = false;
@@ -462,6 +475,10 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + 2 * ncol + cell), dep);
           w = w * ssa;
           if (DEBUG) cAbs++;
+        }
+        if (INTEN) {  // :776-790: weight after the single scattering albedo, before roulette; incoming direction
+          iFlag = 3 + c; iW = w; iDx = dx; iDy = dy; iDz = dz;
+          iEntry = s_fwdOffset[c] + (int)pfiA[(long long)c * nvox + oc] * s_fwdNAngles[c];
         }
         if (p.useRR && w < 0.5f) {  // Russian roulette :805-811, RussianRouletteW = 1
           if (!haveR1) philox4x32_10(event, 1u, idLo, idHi, p.seedLo, p.seedHi, r1);
@@ -555,6 +572,126 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           const float sinTheta = sqrtf(1.0f - mu * mu);
           dx = sinTheta * cosf(phi); dy = sinTheta * sinf(phi); dz = mu;
           needLeg = true;
+          if (INTEN) { iFlag = 1; iW = w; }  // :680-702 reflected weight, Lambertian
+        }
+      }
+      // ---- local estimates: one ray per view direction from every lane with a pending contribution ----
+      // All rays of a direction are parallel, so the lanes of the wave walk in lockstep over similar path
+      // lengths; 1/direction and the step signs are wave-uniform scalars.
+      if (INTEN) {
+        if (__ballot(iFlag != 0) != 0ull) {
+          constexpr float kPi = 3.14159265358979312f;
+          for (int d = 0; d < p.nDir; ++d) {
+            const float *dd = p.dirData + 8 * d;  // uniform address: scalar loads
+            const float ddx = dd[0], ddy = dd[1], ddz = dd[2], fourPiMu = dd[3], jvx = dd[4], jvy = dd[5], jvz = dd[6];
+            const bool fX = ddx >= 0.0f, fY = ddy >= 0.0f, fZ = ddz >= 0.0f;
+            bool act = iFlag != 0;
+            float npf = 0.0f;  // normalizedPhaseFunc :1685-1727
+            if (iFlag == 1) npf = 1.0f / kPi;
+            else if (iFlag == 2) npf = 1.0f / fourPiMu;
+            else if (iFlag >= 3) {
+              float proj = iDx * ddx + iDy * ddy + iDz * ddz;
+              if (fabsf(proj) > 1.0f) proj = copysignf(1.0f, proj);
+              const float ang = acosf(proj);
+              const int nA = s_fwdNAngles[iFlag - 3];
+              const float *t = ((p.useHybrid && nScat <= p.numOrdersOrig) ? p.fwdOrig : p.fwdTables) + iEntry;
+              const float deltaTheta = kPi / (float)(nA - 1);  // lookUpPhaseFuncValsFromTable :1835-1870
+              const int ai = (int)(ang / deltaTheta) + 1;
+              float val;
+              if (ai < nA) {
+                const float wt = 1.0f - (ang - (float)(ai - 1) * deltaTheta) / deltaTheta;
+                val = wt * t[ai - 1] + (1.0f - wt) * t[ai];
+              } else {
+                val = t[nA - 1];
+              }
+              npf = val / fourPiMu;
+            }
+            // Iwabuchi (2006) roulette :1753-1813: phase 2 = free path tauFree, phase 1 = tauMax first
+            float limit = FLT_MAX, tauFree = 0.0f, u2 = 0.0f;
+            int phase = 0;
+            if (p.useRRIntensity && act) {
+              uint32_t r[4];
+              philox4x32_10(event, 0x100u + (uint32_t)d, idLo, idHi, p.seedLo, p.seedHi, r);
+              tauFree = -logf(fmaxf(FLT_MIN, u01(r[0])));
+              u2 = u01(r[1]);
+              if (kPi * npf <= p.zetaMin) { phase = 2; limit = tauFree; }
+              else { phase = 1; limit = -logf(p.zetaMin / fmaxf(FLT_MIN, kPi * npf)); }
+            }
+            // ray state (the photon's own walk state is left alone)
+            double qx = px, qy = py;
+            int rex = ix + (fX ? 1 : 0), rey = offY + iy + (fY ? 1 : 0), rez = offZ + iz + (fZ ? 1 : 0), rcell = cell;
+            float rtx = jvx != 0.0f ? (float)(s_edge[act ? rex : 0] - qx) * jvx : FLT_MAX;
+            float rty = jvy != 0.0f ? (float)(s_edge[act ? rey : 0] - qy) * jvy : FLT_MAX;
+            float rtz = jvz != 0.0f ? (float)(s_edge[act ? rez : 0] - pz) * jvz : FLT_MAX;
+            float rcur = 0.0f, racc = 0.0f;
+            float rext = 0.0f;
+            if (act) rext = gridLds ? s_ext[rcell] : p.ext[rcell];
+            bool outTop = false, outBottom = false;
+            while (__ballot(act) != 0ull) {
+              if (act) {
+                const bool yLtX = rty < rtx;
+                const float m2 = yLtX ? rty : rtx;
+                const bool isZ = rtz < m2;
+                const float tmin = isZ ? rtz : m2;
+                const float accNew = racc + (tmin - rcur) * rext;
+                if (accNew > limit) {  // the optical depth limit is reached inside this cell
+                  if (phase == 1) {    // :1790-1796 continue from the stop point with a fresh free path
+                    rcur = rcur + (limit - racc) / rext;
+                    racc = 0.0f; limit = tauFree; phase = 2;
+                  } else {
+                    act = false;
+                  }
+                } else {
+                  racc = accNew;
+                  rcur = tmin;
+                  if (isZ) {
+                    rez += fZ ? 1 : -1;
+                    if (rez > offZ + p.nz) { act = false; outTop = true; }
+                    else if (rez < offZ) { act = false; outBottom = true; }
+                    else rcell += fZ ? ncol : -ncol;
+                  } else if (yLtX) {
+                    rey += fY ? 1 : -1;
+                    rcell += fY ? p.nx : -p.nx;
+                    if (rey > offY + p.ny) { rey = offY + 1; rcell -= ncol; qy -= p.Ly; }
+                    else if (rey < offY) { rey = offY + p.ny - 1; rcell += ncol; qy += p.Ly; }
+                  } else {
+                    rex += fX ? 1 : -1;
+                    rcell += fX ? 1 : -1;
+                    if (rex > p.nx) { rex = 1; rcell -= p.nx; qx -= p.Lx; }
+                    else if (rex < 0) { rex = p.nx - 1; rcell += p.nx; qx += p.Lx; }
+                  }
+                  if (act) {
+                    rext = gridLds ? s_ext[rcell] : p.ext[rcell];
+                    const int eSel = isZ ? rez : (yLtX ? rey : rex);
+                    const double origin = isZ ? pz : (yLtX ? qy : qx);
+                    const float jv = isZ ? jvz : (yLtX ? jvy : jvx);
+                    const float tNew = (float)(s_edge[eSel] - origin) * jv;
+                    rtz = isZ ? tNew : rtz;
+                    rty = (!isZ && yLtX) ? tNew : rty;
+                    rtx = (!isZ && !yLtX) ? tNew : rtx;
+                  }
+                }
+              }
+            }
+            if (iFlag != 0) {
+              float contrib = 0.0f;
+              if (!p.useRRIntensity) {  // :1745-1752 transmission to the boundary the ray leaves through
+                contrib = (iW * npf) * expf(-racc);
+              } else if (kPi * npf <= p.zetaMin) {  // :1760-1775
+                if (u2 <= kPi * npf / p.zetaMin && outTop) contrib = iW * p.zetaMin / kPi;
+              } else if (outTop) {  // :1782-1806
+                contrib = phase == 1 ? (iW * npf) * expf(-racc) : iW * p.zetaMin / kPi;
+              }
+              if (contrib != 0.0f && (outTop || outBottom)) {  // (a truncated Legendre series can go negative: tallied as is)
+                const int col = outTop ? rcell - ncol * (p.nz - 1) : rcell;
+                const unsigned long long dep = (unsigned long long)__double2ll_rn((double)contrib * kTallyScale);
+                const long long bin = 2LL * ncol + (long long)ncol * p.nz + (long long)d * ncol + col;
+                if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + bin), dep);
+                else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + bin), dep);
+              }
+            }
+          }
+          iFlag = 0;
         }
       }
       STAMP(5);
@@ -691,7 +828,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
 // double sums are reproducible.
 // ---------------------------------------------------------------------------------------
 struct FinishParams {
-  int nx, ny, nz, nBatches, xyRegular;
+  int nx, ny, nz, nBatches, xyRegular, nDir;
   unsigned long long ppb, total, slabStride;
   const long long *slabs;
   const float *relArea;   // [ncol] relative column area (irregular xy)
@@ -730,7 +867,7 @@ __global__ void finish_columns(const FinishParams f) {
 // one thread per column flux element: fold batches in order into S1/S2
 __global__ void finish_column_moments(const FinishParams f) {
   const int ncol = f.nx * f.ny;
-  const long long M = 3 + 3LL * ncol + f.nz + (long long)ncol * f.nz;
+  const long long M = 3 + 3LL * ncol + f.nz + (long long)ncol * f.nz + (long long)f.nDir * ncol;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 3 * ncol) return;
   const int q = i / ncol, col = i % ncol;
@@ -751,7 +888,7 @@ __global__ void finish_column_moments(const FinishParams f) {
 __global__ void finish_volume(const FinishParams f) {
   const int ncol = f.nx * f.ny;
   const long long nvox = (long long)ncol * f.nz;
-  const long long M = 3 + 3LL * ncol + f.nz + nvox;
+  const long long M = 3 + 3LL * ncol + f.nz + nvox + (long long)f.nDir * ncol;
   const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nvox) return;
   const int col = (int)(v % ncol), k = (int)(v / ncol);
@@ -770,6 +907,31 @@ __global__ void finish_volume(const FinishParams f) {
   f.moments[8 + 3 + 3LL * ncol + f.nz + v] += s1;
   f.moments[8 + M + 3 + 3LL * ncol + f.nz + v] += s2;
   f.last[3 + 3LL * ncol + f.nz + v] = lastv;
+}
+
+// intensity(:, :, d) / numPhotonsPerColumn (:369-371), then the driver's RadianceStats moments
+__global__ void finish_intensity(const FinishParams f) {
+  const int ncol = f.nx * f.ny;
+  const long long nvox = (long long)ncol * f.nz;
+  const long long M = 3 + 3LL * ncol + f.nz + nvox + (long long)f.nDir * ncol;
+  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= (long long)ncol * f.nDir) return;
+  const int col = (int)(v % ncol);
+  double s1 = 0, s2 = 0;
+  float lastv = 0;
+  for (int b = 0; b < f.nBatches; b++) {
+    const unsigned long long n = batch_photons(f, b);
+    const float nppc = photons_per_column(f, col, n);
+    const long long raw = f.slabs[(unsigned long long)b * f.slabStride + 2 * ncol + nvox + v];
+    const float x = (float)((double)raw * kTallyInv) / nppc;
+    s1 += (double)x * (double)(long long)n;
+    s2 += (double)(long long)n * ((double)x * (double)x);
+    lastv = x;
+  }
+  const long long off = 3 + 3LL * ncol + f.nz + nvox + v;
+  f.moments[8 + off] += s1;
+  f.moments[8 + M + off] += s2;
+  f.last[off] = lastv;
 }
 
 // One block per (batch, quantity): quantity 0..2 = domain-mean fluxes (reportResults :881-884),
@@ -803,7 +965,7 @@ __global__ void finish_reduce(const FinishParams f) {
 
 __global__ void finish_scalars(const FinishParams f) {
   const int ncol = f.nx * f.ny;
-  const long long M = 3 + 3LL * ncol + f.nz + (long long)ncol * f.nz;
+  const long long M = 3 + 3LL * ncol + f.nz + (long long)ncol * f.nz + (long long)f.nDir * ncol;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q == 0) {  // header: photons and batches done
     f.moments[0] += (double)(long long)f.total;

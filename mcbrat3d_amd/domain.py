@@ -95,6 +95,17 @@ class Domain:
             self.inversePhaseFunctions = [t.inverse_table(tableSize) for t in self.forwardTables]
         return self.inversePhaseFunctions
 
+    def tabulateForwardPhaseFunctions(self, tableSize, hybrid=False, hybridWidth=0.0):
+        """:1872-1935: (tabulatedPhaseFunctions, tabulatedOrigPhaseFunctions), each a list per component of
+        [nEntries, tableSize] arrays; the first holds the hybrid versions when asked for."""
+        from .phase import computeHybridPhaseFunctions
+        key = (int(tableSize), bool(hybrid), float(hybridWidth))
+        if getattr(self, "_fwd_key", None) != key:
+            orig = [t.forward_table(int(tableSize)) for t in self.forwardTables]
+            tab = [computeHybridPhaseFunctions(t, hybridWidth) for t in orig] if hybrid and hybridWidth > 0 else orig
+            self._fwd_key, self._fwd = key, (tab, orig)
+        return self._fwd
+
     def getInfo_Domain(self):
         if self.totalExt is None:
             self.getOpticalPropertiesByComponent()

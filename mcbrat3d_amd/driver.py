@@ -16,15 +16,20 @@ def split_batches(numBatches, rank, world):
     return lo, base + (1 if rank < extra else 0)
 
 
-def unpack_moments(buf, nx, ny, nz):
-    """header(8) + S1[M] + S2[M] -> dict name -> (S1, S2) in [ix, iy(, iz)] index order."""
+def unpack_moments(buf, nx, ny, nz, nDirections=None):
+    """header(8) + S1[M] + S2[M] -> dict name -> (S1, S2) in [ix, iy(, iz | direction)] index order."""
     ncol, nvox = nx * ny, nx * ny * nz
     M = 3 + 3 * ncol + nz + nvox
+    if nDirections is None:  # the length tells
+        nDirections = ((len(buf) - 8) // 2 - M) // ncol
+    M += nDirections * ncol
     S1, S2 = buf[8:8 + M], buf[8 + M:8 + 2 * M]
     out = {"totalPhotons": buf[0], "batches": buf[1]}
     names = [("meanFluxUp", 1, None), ("meanFluxDown", 1, None), ("meanFluxAbsorbed", 1, None),
              ("fluxUp", ncol, (ny, nx)), ("fluxDown", ncol, (ny, nx)), ("fluxAbsorbed", ncol, (ny, nx)),
              ("absorbedProfile", nz, None), ("absorbedVolume", nvox, (nz, ny, nx))]
+    if nDirections > 0:
+        names.append(("intensity", nDirections * ncol, (nDirections, ny, nx)))
     o = 0
     for name, n, shp in names:
         a, b = S1[o:o + n], S2[o:o + n]

@@ -16,6 +16,9 @@ import numpy as np
 from ._capi import Counters, FATE_DTYPE, McbratError, check, lib, ptr
 
 defaultMinInverseTableSize = 9001  # :24-25
+defaultMinForwardTableSize = 9001
+defaultHybridPhaseFunWidth, maxHybridPhaseFunWidth = 7.0, 30.0  # :26-27
+defaultZetaMin = 0.3  # :29
 
 
 class RandomNumberSequence:
@@ -48,6 +51,19 @@ class Integrator:
         self.useRayTracing = True
         self.useRussianRoulette = True
         self.LW_flag = -1.0
+        # radiance by local estimation (:72-97)
+        self.computeIntensity = False
+        self.intensityMus = np.zeros(0, np.float32)
+        self.intensityPhis = np.zeros(0, np.float32)
+        self.minForwardTableSize = defaultMinForwardTableSize
+        self.useHybridPhaseFunsForIntenCalcs = False
+        self.hybridPhaseFunWidth = defaultHybridPhaseFunWidth
+        self.numOrdersOrigPhaseFunIntenCalcs = 0
+        self.useRussianRouletteForIntensity = False
+        self.zetaMin = defaultZetaMin
+        self.limitIntensityContributions = False
+        self.maxIntensityContribution = float(np.finfo(np.float32).max)
+        self._intensity_token = None
         self._domain_token = None
         self._source_token = None
         self._dims = None
@@ -83,9 +99,50 @@ class Integrator:
 
     # -- specifyParameters ------------------------------------------------------------
     def specifyParameters(self, minInverseTableSize=None, useRayTracing=None, useRussianRoulette=None, LW_flag=None,
-                          computeIntensity=None, intensityMus=None, intensityPhis=None, surfaceBDRF=None, **unsupported):
-        if computeIntensity or intensityMus is not None or intensityPhis is not None:
-            raise McbratError("specifyParameters: intensity (radiance) calculations are outside this integrator's path")
+                          computeIntensity=None, intensityMus=None, intensityPhis=None, minForwardTableSize=None,
+                          useRussianRouletteForIntensity=None, zetaMin=None, useHybridPhaseFunsForIntenCalcs=None,
+                          hybridPhaseFunWidth=None, numOrdersOrigPhaseFunIntenCalcs=None,
+                          limitIntensityContributions=None, maxIntensityContribution=None, surfaceBDRF=None,
+                          **unsupported):
+        # intensity keywords, :1130-1160 and :1186-1283
+        if (intensityMus is None) != (intensityPhis is None):
+            raise McbratError("specifyParameters: Both or neither of intensityMus, intensityPhis must be supplied")
+        if intensityMus is not None:
+            mus = np.ascontiguousarray(intensityMus, np.float32).reshape(-1)
+            phis = np.ascontiguousarray(intensityPhis, np.float32).reshape(-1)
+            if mus.size != phis.size:
+                raise McbratError("specifyParameters: intensityMus, intensityPhis must be the same length")
+            self.intensityMus, self.intensityPhis = mus, phis
+            self.computeIntensity = mus.size > 0
+        if computeIntensity is not None:
+            if computeIntensity and self.intensityMus.size == 0:
+                raise McbratError("specifyParameters: Can't compute intensity without specifying directions.")
+            if not computeIntensity and intensityMus is None:
+                self.computeIntensity = False
+        if minForwardTableSize is not None:
+            self.minForwardTableSize = max(int(minForwardTableSize), defaultMinForwardTableSize)
+            self._domain_token = None
+        if useRussianRouletteForIntensity is not None:
+            self.useRussianRouletteForIntensity = bool(useRussianRouletteForIntensity)
+        if zetaMin is not None and zetaMin >= 0.0:  # :1194-1201 (a negative value is ignored with a warning)
+            self.zetaMin = float(zetaMin)
+        if useHybridPhaseFunsForIntenCalcs is not None:
+            self.useHybridPhaseFunsForIntenCalcs = bool(useHybridPhaseFunsForIntenCalcs)
+            self._domain_token = None
+        if hybridPhaseFunWidth is not None:  # :1108-1114, :1209-1215
+            if hybridPhaseFunWidth > maxHybridPhaseFunWidth or hybridPhaseFunWidth < 0.0:
+                raise McbratError("specifyParameters: hybridPhaseFunWidth out of range (0 to 30degrees).")
+            self.hybridPhaseFunWidth = float(hybridPhaseFunWidth) if 0 < hybridPhaseFunWidth < maxHybridPhaseFunWidth \
+                else defaultHybridPhaseFunWidth
+            self._domain_token = None
+        if numOrdersOrigPhaseFunIntenCalcs is not None:
+            if numOrdersOrigPhaseFunIntenCalcs < 0:
+                raise McbratError("specifyParameters: numOrdersOrigPhaseFunIntenCalcs must be >= 0")
+            self.numOrdersOrigPhaseFunIntenCalcs = int(numOrdersOrigPhaseFunIntenCalcs)
+        if limitIntensityContributions is not None:
+            self.limitIntensityContributions = bool(limitIntensityContributions)
+        if maxIntensityContribution is not None and maxIntensityContribution > 0.0:
+            self.maxIntensityContribution = float(maxIntensityContribution)
         if surfaceBDRF is not None:
             raise McbratError("specifyParameters: only the Lambertian surface is supported")
         for k, v in unsupported.items():
@@ -102,6 +159,25 @@ class Integrator:
             self.LW_flag = float(LW_flag)
         self._check(self._lib.mcbrat_specify_parameters(self._ctx, int(self.useRayTracing),
                                                         int(self.useRussianRoulette), C.c_float(self.LW_flag)))
+        self._push_intensity()
+
+    def _push_intensity(self):
+        n = int(self.intensityMus.size) if self.computeIntensity else 0
+        token = (n, self.intensityMus.tobytes(), self.intensityPhis.tobytes(), self.useRussianRouletteForIntensity, self.zetaMin,
+                 self.useHybridPhaseFunsForIntenCalcs, self.numOrdersOrigPhaseFunIntenCalcs, self.limitIntensityContributions,
+                 self.maxIntensityContribution)
+        if token == self._intensity_token:
+            return
+        self._check(self._lib.mcbrat_specify_intensity(
+            self._ctx, n, ptr(self.intensityMus) if n else None, ptr(self.intensityPhis) if n else None,
+            int(self.useRussianRouletteForIntensity), C.c_float(self.zetaMin), int(self.useHybridPhaseFunsForIntenCalcs),
+            int(self.numOrdersOrigPhaseFunIntenCalcs), int(self.limitIntensityContributions),
+            C.c_float(self.maxIntensityContribution)))
+        self._intensity_token = token
+        self._domain_token = None  # forward tables go with the optics
+
+    def numIntensityDirections(self):
+        return int(self.intensityMus.size) if self.computeIntensity else 0
 
     def setTuning(self, blocksPerCU=-1, eventThreshold=0, maxBatchesInFlight=-1, privateTallies=-1, blockSize=-1,
                   launchThreshold=0, surfaceThreshold=0, brickLayout=-1):
@@ -125,7 +201,8 @@ class Integrator:
 
     # -- computeRadiativeTransfer -------------------------------------------------------
     def _load_domain(self, dom):
-        token = (id(dom), id(dom.totalExt), self.minInverseTableSize)
+        token = (id(dom), id(dom.totalExt), self.minInverseTableSize, self.numIntensityDirections() > 0,
+                 self.minForwardTableSize, self.useHybridPhaseFunsForIntenCalcs, self.hybridPhaseFunWidth)
         if token == self._domain_token:
             return
         info = dom.getInfo_Domain()
@@ -141,6 +218,14 @@ class Integrator:
         for c, t in enumerate(tables):
             t = np.ascontiguousarray(t, np.float32)
             self._check(self._lib.mcbrat_set_inverse_table(self._ctx, c + 1, t.shape[1], t.shape[0], ptr(t)))
+        if self.numIntensityDirections() > 0:  # :281-285 forward tables only when intensity is computed
+            tab, orig = dom.tabulateForwardPhaseFunctions(self.minForwardTableSize, self.useHybridPhaseFunsForIntenCalcs,
+                                                          self.hybridPhaseFunWidth)
+            for c, (t, o) in enumerate(zip(tab, orig)):
+                t = np.ascontiguousarray(t, np.float32)
+                o = np.ascontiguousarray(o, np.float32)
+                self._check(self._lib.mcbrat_set_forward_table(self._ctx, c + 1, t.shape[1], t.shape[0], ptr(t),
+                                                               ptr(o) if self.useHybridPhaseFunsForIntenCalcs else None))
         self._domain_token = token
         self._source_token = None
 
@@ -186,9 +271,16 @@ class Integrator:
         self._check(self._lib.mcbrat_report_results(self._ctx, C.addressof(mu), C.addressof(md), C.addressof(ma), ptr(up),
                                                     ptr(dn), ptr(ab), ptr(prof), ptr(vol)))
         f2 = lambda a: a.reshape(ny, nx).T  # noqa: E731  -> [ix, iy]
-        return dict(meanFluxUp=mu.value, meanFluxDown=md.value, meanFluxAbsorbed=ma.value,
-                    fluxUp=f2(up), fluxDown=f2(dn), fluxAbsorbed=f2(ab), absorbedProfile=prof,
-                    volumeAbsorption=vol.reshape(nz, ny, nx).transpose(2, 1, 0))
+        res = dict(meanFluxUp=mu.value, meanFluxDown=md.value, meanFluxAbsorbed=ma.value,
+                   fluxUp=f2(up), fluxDown=f2(dn), fluxAbsorbed=f2(ab), absorbedProfile=prof,
+                   volumeAbsorption=vol.reshape(nz, ny, nx).transpose(2, 1, 0))
+        nd = self.numIntensityDirections()
+        if nd > 0:  # meanIntensity(direction), intensity(x, y, direction) :980-1010
+            mean_i = np.zeros(nd, np.float32)
+            inten = np.zeros(nd * nx * ny, np.float32)
+            self._check(self._lib.mcbrat_report_intensity(self._ctx, ptr(mean_i), ptr(inten)))
+            res.update(meanIntensity=mean_i, intensity=inten.reshape(nd, ny, nx).transpose(2, 1, 0))
+        return res
 
     # -- batch moments (what the driver keeps in *Stats and reduces over processes) -----
     def momentsLength(self):

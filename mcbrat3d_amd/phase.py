@@ -47,6 +47,21 @@ class PhaseFunction:
         return out
 
 
+    def forward_table(self, nAngles):
+        """getPhaseFunctionValues at nAngles angles equally spaced on [0, pi] (tabulateForwardPhaseFunctions,
+        src/opticalProperties.f95:1914-1916)."""
+        out = np.zeros(nAngles, np.float32)
+        if self.legendreCoefficients is not None:
+            rc = lib().mcbrat_forward_table_legendre(len(self.legendreCoefficients), ptr(self.legendreCoefficients),
+                                                     nAngles, ptr(out))
+        else:
+            rc = lib().mcbrat_forward_table_tabulated(len(self.scatteringAngle), ptr(self.scatteringAngle),
+                                                      ptr(self.value), nAngles, ptr(out))
+        if rc != 0:
+            raise McbratError("tabulatePhaseFunctions: can't compute forward tables.")
+        return out
+
+
 class PhaseFunctionTable:
     def __init__(self, phaseFunctions, key=None, tableDescription=""):
         self.phaseFunctions = list(phaseFunctions)
@@ -67,6 +82,20 @@ class PhaseFunctionTable:
     def inverse_table(self, nSteps):
         """computeInversePhaseFuncTable (:26-64): [nEntries, nSteps]."""
         return np.stack([p.inverse_table(nSteps) for p in self.phaseFunctions])
+
+
+    def forward_table(self, nAngles):
+        """[nEntries, nAngles]"""
+        return np.stack([p.forward_table(nAngles) for p in self.phaseFunctions])
+
+
+def computeHybridPhaseFunctions(values, GaussianWidth):
+    """src/opticalProperties.f95:1937-2009 on values[nEntries, nAngles] (angles equally spaced on [0, pi])."""
+    v = np.ascontiguousarray(values, np.float32)
+    out = np.zeros_like(v)
+    if lib().mcbrat_hybrid_phase_functions(v.shape[1], v.shape[0], ptr(v), float(GaussianWidth), ptr(out)) != 0:
+        raise McbratError("computeHybridPhaseFunctions: invalid table or width")
+    return out
 
 
 def new_PhaseFunction(*args, **kw):

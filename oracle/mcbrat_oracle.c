@@ -795,6 +795,10 @@ static void intensity_contribution(const orc_problem *P, const orc_intensity *I,
         float tau = orc_accumulate_extinction(P, D, pos, idx, 1, tauMax, NULL);
         if (idx[2] >= zIndexMax && tau >= 0.0f) {
           contribution = (photonWeight * normalizedPhaseFunc) * expf(-tau);
+        } else if (tau >= 0.0f && idx[2] < 1) {
+          /* a downward direction left through the surface: the reference would restart the walk with
+           * zIndex = 0 (out of bounds); roulette is only meaningful for upward directions */
+          contribution = 0.0f;
         } else if (tau >= 0.0f) {
           (void)orc_accumulate_extinction(P, D, pos, idx, 1, tauFree, NULL);
           contribution = idx[2] >= zIndexMax ? photonWeight * I->zetaMin / Pi : 0.0f;
