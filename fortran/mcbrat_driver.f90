@@ -62,7 +62,10 @@ program mcbrat_driver
   real,    allocatable :: table(:,:)
   real(8), allocatable :: moments(:)
   real(8), allocatable :: meanStats(:,:), fluxUpStats(:,:,:), fluxDownStats(:,:,:), fluxAbsorbedStats(:,:,:), &
-                          absorbedProfileStats(:,:)
+                          absorbedProfileStats(:,:), RadianceStats(:,:,:,:)
+  real,    allocatable :: forwardTable(:,:), legendreCoefficients(:)
+  integer :: numRadDir, off
+  logical :: computeIntensity
   real :: t0, t1
 
   if (command_argument_count() < 1) stop "usage: mcbrat_driver <namelist file>"
@@ -88,6 +91,18 @@ program mcbrat_driver
   call setOpticalProperties(mcIntegrator, totalExt, cumExt, ssa, phaseFuncI, albedo, ierr); call check("setOpticalProperties")
   call specifyParameters(mcIntegrator, useRayTracing, useRussianRoulette, LW_flag, ierr); call check("specifyParameters")
   call loadTables()
+  ! intensity directions: entries with |mu| > 0, only if a file will hold them (monteCarloDriver.f95:279-282, :547-594)
+  numRadDir = count(abs(intensityMus(:)) > 0.)
+  computeIntensity = numRadDir > 0 .and. len_trim(outputRadFile) > 0
+  if (computeIntensity) then
+    if (.not. allocated(legendreCoefficients)) stop "intensity needs the phase function of a builtin domain"
+    allocate(forwardTable(max(nPhaseIntervals, 9001), 1))
+    call forwardTableLegendre(legendreCoefficients, forwardTable(:, 1), ierr); call check("forwardTableLegendre")
+    call specifyIntensity(mcIntegrator, pack(intensityMus, abs(intensityMus) > 0.), pack(intensityPhis, abs(intensityMus) > 0.), &
+                          useRussianRouletteForIntensity, zetaMin, .false., numOrdersOrigPhaseFunIntenCalcs, ierr)
+    call check("specifyParameters")
+    call setForwardTable(mcIntegrator, 1, forwardTable, forwardTable, ierr); call check("setForwardTable")
+  end if
   call setSolarSource(mcIntegrator, solarMu, solarAzimuth, ierr); call check("setSolarSource")
   call resetMoments(mcIntegrator, ierr); call check("resetMoments")
   call cpu_time(t1)
@@ -121,6 +136,17 @@ program mcbrat_driver
   print '(A,3(2X,F9.6,A,F9.6))', " mean flux up/down/absorbed:", meanStats(1,1), " +-", meanStats(1,2), &
         meanStats(2,1), " +-", meanStats(2,2), meanStats(3,1), " +-", meanStats(3,2)
   if (len_trim(outputFluxFile) > 0) call writeFluxASCII()
+  if (computeIntensity) then   ! RadianceStats :1047-1050, :1221-1228
+    allocate(RadianceStats(nx, ny, numRadDir, 2))
+    off = 3 + 3*ncol + nz + ncol*nz
+    do k = 1, 2
+      RadianceStats(:, :, :, k) = reshape(moments(8 + (k-1)*M + off + 1 : 8 + (k-1)*M + off + ncol*numRadDir), (/ nx, ny, numRadDir /))
+    end do
+    RadianceStats(:, :, :, :) = solarFlux * RadianceStats(:, :, :, :) / totalNumPhotons
+    RadianceStats(:, :, :, 2) = solarFlux * RadianceStats(:, :, :, 2)
+    RadianceStats(:, :, :, 2) = sqrt(max(0.0_8, RadianceStats(:, :, :, 2) - RadianceStats(:, :, :, 1)**2) / (batchesCompleted - 1))
+    call writeRadianceASCII()
+  end if
   call finalize_Integrator(mcIntegrator)
 
 contains
@@ -177,6 +203,7 @@ contains
     end if
     cumExt = 1.0_8; ssa = w0; phaseFuncI = 1
     coefficients = g ** (/ (i, i = 1, nLegendreCoefficients) /)
+    allocate(legendreCoefficients(nLegendreCoefficients)); legendreCoefficients = coefficients
     nSteps = max(nPhaseIntervals, 9001); nEntries = 1
     allocate(table(nSteps, 1))
     call inverseTableLegendre(coefficients, table(:, 1), ierr)
@@ -232,4 +259,34 @@ contains
     end do
     close (2)
   end subroutine writeFluxASCII
+
+  subroutine writeRadianceASCII()   ! writeResults_ASCII, radiance part, monteCarloDriver.f95:1459-1494
+    real :: mus(numRadDir), phis(numRadDir)
+    mus = pack(intensityMus, abs(intensityMus) > 0.); phis = pack(intensityPhis, abs(intensityMus) > 0.)
+    open (unit = 2, file = outputRadFile, status = 'unknown')
+    write (2,'(A)') '!   I3RC Monte Carlo 3D Solar Radiative Transfer: Radiance'
+    write (2,'(A,A60)') '!  Property_File=', physDomainFile
+    write (2,'(A,I10)')  '!  Num_Photons=', int(totalNumPhotons, 8)
+    write (2,'(A,L1,A,L1)') '!  PhotonTracing=', useRayTracing, '    Russian_Roulette=', useRussianRoulette
+    write (2,'(A,L1,A,F5.2)') '!  Hybrid_Phase_Func_for_Radiance=', useHybridPhaseFunsForIntenCalcs, &
+                              '   Gaussian_Phase_Func_Width_deg=', hybridPhaseFunWidth
+    write (2,'(A,L1,A,F5.2)') '!  Intensity_uses_Russian_Roulette=', useRussianRouletteForIntensity, &
+                              '   Intensity_Russian_Roulette_zeta_min=', zetaMin
+    write (2,'(A,L1,A,F5.2)') '!  limited_intensity_contributions=', limitIntensityContributions, &
+                              '   max_intensity_contribution=', maxIntensityContribution
+    write (2,'(A,E13.6,A,F10.7,A,F7.3)') '!  Solar_Flux=', solarFlux, '   Solar_Mu=', solarMu, '   Solar_Phi=', solarAzimuth
+    write (2,'(A,F7.4)') '!  Lambertian_Surface_Albedo=', albedo
+    write (2,'(A)')  '!  Output_Type= Pixel Radiance'
+    write (2,'(A,F7.3,3(A,I4))') '!  RADIANCE AT Z=', zPosition(nz+1), '   NXO=', nx, '   NYO=', ny, '   NDIR=', numRadDir
+    write (2,'(A)') '!   X      Y         Radiance (Mean, StdErr)'
+    do k = 1, numRadDir
+      write (2,'(A,1X,F8.5,1X,F6.2,2X,A)') '! ', mus(k), phis(k), '<- (mu,phi)'
+      do j = 1, ny
+        do i = 1, nx
+          write (2,'(2(F7.3),2(1X,F9.4))') sum(xPosition(i:i+1))/2., sum(yPosition(j:j+1))/2., RadianceStats(i,j,k,1:2)
+        end do
+      end do
+    end do
+    close (2)
+  end subroutine writeRadianceASCII
 end program mcbrat_driver

@@ -25,7 +25,8 @@ module mcbrat_hip_integrator
             setOpticalProperties, setInverseTable, setSolarSource, setEmissionSource, &
             specifyParameters, computeRadiativeTransfer, reportResults, &
             resetMoments, getMoments, momentsLength, lastMessage, &
-            inverseTableLegendre, lastTraceMilliseconds, setAsynchronous, synchronize
+            inverseTableLegendre, lastTraceMilliseconds, setAsynchronous, synchronize, &
+            specifyIntensity, setForwardTable, reportIntensity, forwardTableLegendre
 
   interface
     function mcbrat_create(device) bind(C, name="mcbrat_create") result(ctx)
@@ -116,6 +117,36 @@ module mcbrat_hip_integrator
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: ctx
       real(c_double), intent(out) :: buf(*)
+      integer(c_int) :: rc
+    end function
+    function mcbrat_specify_intensity(ctx, nDir, mus, phis, useRRI, zetaMin, useHybrid, numOrdersOrig, limitC, maxC) &
+        bind(C, name="mcbrat_specify_intensity") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_float
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: nDir, useRRI, useHybrid, numOrdersOrig, limitC
+      real(c_float), intent(in) :: mus(*), phis(*)
+      real(c_float), value :: zetaMin, maxC
+      integer(c_int) :: rc
+    end function
+    function mcbrat_set_forward_table(ctx, component, nAngles, nEntries, table, origTable) &
+        bind(C, name="mcbrat_set_forward_table") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_float
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: component, nAngles, nEntries
+      real(c_float), intent(in) :: table(*), origTable(*)
+      integer(c_int) :: rc
+    end function
+    function mcbrat_report_intensity(ctx, meanIntensity, intensity) bind(C, name="mcbrat_report_intensity") result(rc)
+      import :: c_ptr, c_int, c_float
+      type(c_ptr), value :: ctx
+      real(c_float), intent(out) :: meanIntensity(*), intensity(*)
+      integer(c_int) :: rc
+    end function
+    function mcbrat_forward_table_legendre(nCoef, coef, nAngles, table) bind(C, name="mcbrat_forward_table_legendre") result(rc)
+      import :: c_int, c_int32_t, c_float
+      integer(c_int32_t), value :: nCoef, nAngles
+      real(c_float), intent(in) :: coef(*)
+      real(c_float), intent(out) :: table(*)
       integer(c_int) :: rc
     end function
     function mcbrat_set_async(ctx, enable) bind(C, name="mcbrat_set_async") result(rc)
@@ -285,6 +316,46 @@ contains
     integer, intent(out) :: ierr
     ierr = mcbrat_get_moments(this%ctx, buffer)
   end subroutine getMoments
+  ! specifyParameters, intensity keywords (:1046-1292): directions and variance-reduction choices
+  subroutine specifyIntensity(this, intensityMus, intensityPhis, useRussianRouletteForIntensity, zetaMin, &
+                              useHybridPhaseFunsForIntenCalcs, numOrdersOrigPhaseFunIntenCalcs, ierr)
+    type(integrator),   intent(inout) :: this
+    real, dimension(:), intent(in)    :: intensityMus, intensityPhis
+    logical,            intent(in)    :: useRussianRouletteForIntensity, useHybridPhaseFunsForIntenCalcs
+    real,               intent(in)    :: zetaMin
+    integer,            intent(in)    :: numOrdersOrigPhaseFunIntenCalcs
+    integer,            intent(out)   :: ierr
+    ierr = mcbrat_specify_intensity(this%ctx, int(size(intensityMus), c_int32_t), intensityMus, intensityPhis, &
+                                    merge(1_c_int32_t, 0_c_int32_t, useRussianRouletteForIntensity), zetaMin, &
+                                    merge(1_c_int32_t, 0_c_int32_t, useHybridPhaseFunsForIntenCalcs), &
+                                    int(numOrdersOrigPhaseFunIntenCalcs, c_int32_t), 0_c_int32_t, huge(1.0))
+  end subroutine specifyIntensity
+  ! tabulatedPhaseFunctions(component)%values / tabulatedOrigPhaseFunctions(component)%values (nAngles, nEntries)
+  subroutine setForwardTable(this, component, values, origValues, ierr)
+    type(integrator),     intent(inout) :: this
+    integer,              intent(in)    :: component
+    real, dimension(:,:), intent(in)    :: values, origValues
+    integer,              intent(out)   :: ierr
+    ierr = mcbrat_set_forward_table(this%ctx, int(component, c_int32_t), int(size(values, 1), c_int32_t), &
+                                    int(size(values, 2), c_int32_t), values, origValues)
+  end subroutine setForwardTable
+  subroutine reportIntensity(this, meanIntensity, intensity, ierr)   ! reportResults(meanIntensity, intensity) :980-1010
+    type(integrator),       intent(in)  :: this
+    real, dimension(:),     intent(out) :: meanIntensity
+    real, dimension(:,:,:), intent(out) :: intensity
+    integer,                intent(out) :: ierr
+    if (size(intensity, 1) /= this%numX .or. size(intensity, 2) /= this%numY .or. size(intensity, 3) /= size(meanIntensity)) then
+      ierr = 1   ! "reportResults: intensity array has wrong dimensions."
+      return
+    end if
+    ierr = mcbrat_report_intensity(this%ctx, meanIntensity, intensity)
+  end subroutine reportIntensity
+  subroutine forwardTableLegendre(coefficients, table, ierr)   ! tabulateForwardPhaseFunctions for one Legendre entry
+    real, dimension(:), intent(in)  :: coefficients
+    real, dimension(:), intent(out) :: table
+    integer,            intent(out) :: ierr
+    ierr = mcbrat_forward_table_legendre(int(size(coefficients), c_int32_t), coefficients, int(size(table), c_int32_t), table)
+  end subroutine forwardTableLegendre
   ! Per-batch callers (the driver's loop, monteCarloDriver.f95:1008): let consecutive calls overlap on the GPU;
   ! reportResults / getMoments synchronise by themselves.
   subroutine setAsynchronous(this, enable, ierr)

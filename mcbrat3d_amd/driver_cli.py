@@ -14,12 +14,15 @@ import time
 import numpy as np
 
 DEFAULTS = {  # monteCarloDriver.f95:58-99
-    "radiativetransfer": dict(solarmu=1.0, solarazimuth=0.0, surfacetemp=300.0, lw_flag=-1.0, numlambda=1, calcrayl=True),
+    "radiativetransfer": dict(solarmu=1.0, solarazimuth=0.0, surfacetemp=300.0, lw_flag=-1.0, numlambda=1, calcrayl=True,
+                              intensitymus=[], intensityphis=[]),
     "montecarlo": dict(numphotonsperbatch=0, numbatches=100, iseed=10, nphaseintervals=10001),
-    "algorithms": dict(useraytracing=True, userussianroulette=True),
+    "algorithms": dict(useraytracing=True, userussianroulette=True, usehybridphasefunsforintencalcs=False,
+                       hybridphasefunwidth=7.0, numordersorigphasefunintencalcs=0, userussianrouletteforintensity=True,
+                       zetamin=0.3, limitintensitycontributions=False, maxintensitycontribution=77.0),
     "output": dict(reportvolumeabsorption=False, reportabsorptionprofile=False),
     "filenames": dict(physdomainfile="", domainfilename="", outputfluxfile="", outputabsproffile="", outputabsvolumefile="",
-                      outputnetcdffile=""),
+                      outputnetcdffile="", outputradfile=""),
 }
 
 
@@ -86,6 +89,34 @@ def writeResults_ASCII(path, cfg, domainName, stats, xe, ye, ze, solarFlux, albe
                                 for k in ("fluxUp", "fluxDown", "fluxAbsorbed")) + "\n")
 
 
+def writeResults_ASCII_radiance(path, cfg, domainName, stats, xe, ye, ze, solarFlux, albedo, mus, phis):
+    """The radiance file, monteCarloDriver.f95:1459-1494."""
+    nx, ny, nz = len(xe) - 1, len(ye) - 1, len(ze) - 1
+    b = lambda v: "T" if v else "F"  # noqa: E731
+    with open(path, "w") as f:
+        f.write("!   I3RC Monte Carlo 3D Solar Radiative Transfer: Radiance\n")
+        f.write("!  Property_File=%60s\n" % domainName[:60])
+        f.write("!  Num_Photons=%10d\n" % int(stats["totalPhotons"]))
+        f.write("!  PhotonTracing=%s    Russian_Roulette=%s\n" % (b(cfg["useraytracing"]), b(cfg["userussianroulette"])))
+        f.write("!  Hybrid_Phase_Func_for_Radiance=%s   Gaussian_Phase_Func_Width_deg=%5.2f\n"
+                % (b(cfg["usehybridphasefunsforintencalcs"]), cfg["hybridphasefunwidth"]))
+        f.write("!  Intensity_uses_Russian_Roulette=%s   Intensity_Russian_Roulette_zeta_min=%5.2f\n"
+                % (b(cfg["userussianrouletteforintensity"]), cfg["zetamin"]))
+        f.write("!  limited_intensity_contributions=%s   max_intensity_contribution=%5.2f\n"
+                % (b(cfg["limitintensitycontributions"]), cfg["maxintensitycontribution"]))
+        f.write("!  Solar_Flux=%13.6E   Solar_Mu=%10.7f   Solar_Phi=%7.3f\n" % (solarFlux, cfg["solarmu"], cfg["solarazimuth"]))
+        f.write("!  Lambertian_Surface_Albedo=%7.4f\n" % albedo)
+        f.write("!  Output_Type= Pixel Radiance\n")
+        f.write("!  RADIANCE AT Z=%7.3f   NXO=%4d   NYO=%4d   NDIR=%4d\n" % (ze[nz], nx, ny, len(mus)))
+        f.write("!   X      Y         Radiance (Mean, StdErr)\n")
+        for k in range(len(mus)):
+            f.write("!  %8.5f %6.2f  <- (mu,phi)\n" % (mus[k], phis[k]))
+            for j in range(ny):
+                for i in range(nx):
+                    f.write("%7.3f%7.3f %9.4f %9.4f\n" % (0.5 * (xe[i] + xe[i + 1]), 0.5 * (ye[j] + ye[j + 1]),
+                                                        stats["intensity"][i, j, k], stats["intensity_StdErr"][i, j, k]))
+
+
 def builtin_domain(name):
     """Domain-Files/i3rcStepCloud.f95, planeParallel.f95 (km)."""
     import mcbrat3d_amd as M
@@ -133,6 +164,23 @@ def main(argv=None):
     integ = M.new_Integrator(dom, device=local)
     integ.specifyParameters(minInverseTableSize=cfg["nphaseintervals"], useRayTracing=cfg["useraytracing"],
                             useRussianRoulette=cfg["userussianroulette"], LW_flag=cfg["lw_flag"])
+    # intensity directions: every entry with |mu| > 0, and only if a file will hold them (monteCarloDriver.f95:279-282)
+    mus = np.atleast_1d(np.asarray(cfg["intensitymus"], np.float32))
+    phis = np.atleast_1d(np.asarray(cfg["intensityphis"], np.float32))
+    if phis.size < mus.size:
+        phis = np.concatenate([phis, np.zeros(mus.size - phis.size, np.float32)])
+    keep = np.abs(mus) > 0.0
+    mus, phis = mus[keep], phis[:mus.size][keep]
+    computeIntensity = mus.size > 0 and bool(cfg["outputradfile"] or cfg["outputnetcdffile"])
+    if computeIntensity:  # :547-552, :579-594
+        integ.specifyParameters(minForwardTableSize=cfg["nphaseintervals"], intensityMus=mus, intensityPhis=phis,
+                                computeIntensity=True,
+                                useHybridPhaseFunsForIntenCalcs=cfg["usehybridphasefunsforintencalcs"],
+                                hybridPhaseFunWidth=cfg["hybridphasefunwidth"],
+                                numOrdersOrigPhaseFunIntenCalcs=cfg["numordersorigphasefunintencalcs"],
+                                useRussianRouletteForIntensity=cfg["userussianrouletteforintensity"], zetaMin=cfg["zetamin"],
+                                limitIntensityContributions=cfg["limitintensitycontributions"],
+                                maxIntensityContribution=cfg["maxintensitycontribution"])
     photons = M.new_PhotonStream(cfg["solarmu"], cfg["solarazimuth"], numberOfPhotons=cfg["numphotonsperbatch"] * cfg["numbatches"])
     moments = None
     if dist is not None:
@@ -148,13 +196,22 @@ def main(argv=None):
         xe, ye, ze = dom.xPosition, dom.yPosition, dom.zPosition
         if cfg["outputfluxfile"]:
             writeResults_ASCII(cfg["outputfluxfile"], cfg, domfile, stats, xe, ye, ze, 1.0, dom.surfaceAlbedo)
+        if cfg["outputradfile"] and computeIntensity:
+            writeResults_ASCII_radiance(cfg["outputradfile"], cfg, domfile, stats, xe, ye, ze, 1.0, dom.surfaceAlbedo, mus, phis)
         if cfg["outputnetcdffile"]:
             ncio.writeResults_netcdf(cfg["outputnetcdffile"], domfile, stats, xe, ye, ze, solarFlux=1.0, solarMu=cfg["solarmu"],
                                      solarAzimuth=cfg["solarazimuth"], surfaceAlbedo=dom.surfaceAlbedo, iseed=cfg["iseed"],
                                      nPhaseIntervals=cfg["nphaseintervals"],
                                      reportAbsorptionProfile=cfg["reportabsorptionprofile"],
                                      reportVolumeAbsorption=cfg["reportvolumeabsorption"],
-                                     cpuTimeTotal=time.time() - t0, cpuTimeSetup=setup, numProcs=world)
+                                     cpuTimeTotal=time.time() - t0, cpuTimeSetup=setup, numProcs=world,
+                                     intensityMus=mus if computeIntensity else None,
+                                     intensityPhis=phis if computeIntensity else None,
+                                     useHybridPhaseFunsForIntenCalcs=cfg["usehybridphasefunsforintencalcs"],
+                                     hybridPhaseFunWidth=cfg["hybridphasefunwidth"],
+                                     useRussianRouletteForIntensity=cfg["userussianrouletteforintensity"], zetaMin=cfg["zetamin"],
+                                     limitIntensityContributions=cfg["limitintensitycontributions"],
+                                     maxIntensityContribution=cfg["maxintensitycontribution"])
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

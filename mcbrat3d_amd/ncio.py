@@ -148,7 +148,9 @@ def read_Domain(fileName):
 def writeResults_netcdf(outputFileName, domainFileName, stats, xPosition, yPosition, zPosition, solarFlux=1.0, solarMu=1.0,
                         solarAzimuth=0.0, surfaceAlbedo=0.0, iseed=10, nPhaseIntervals=10001, useRayTracing=True,
                         reportAbsorptionProfile=False, reportVolumeAbsorption=False, cpuTimeTotal=0.0, cpuTimeSetup=0.0,
-                        numProcs=1):
+                        numProcs=1, intensityMus=None, intensityPhis=None, useHybridPhaseFunsForIntenCalcs=False,
+                        hybridPhaseFunWidth=0.0, useRussianRouletteForIntensity=False, zetaMin=0.0,
+                        limitIntensityContributions=False, maxIntensityContribution=0.0):
     """monteCarloDriver.f95:1499-1807.  `stats` is driver.statistics(...) output ([ix, iy(, iz)] arrays)."""
     xe, ye, ze = (np.asarray(a, np.float64) for a in (xPosition, yPosition, zPosition))
     f = netcdf_file(outputFileName, "w", version=2)  # nf90_64bit_offset (:1559)
@@ -164,12 +166,12 @@ def writeResults_netcdf(outputFileName, domainFileName, stats, xPosition, yPosit
         f.Random_number_seed = np.int32(iseed)
         f.Phase_function_table_sizes = np.int32(nPhaseIntervals)
         f.Algorithm = "Ray_tracing" if useRayTracing else "Max_cross_section"
-        f.Intensity_uses_hyrbid_phase_functions = np.int32(0)  # (sic) :1583
-        f.Hybrid_phase_function_width = np.float32(0.0)
-        f.Intensity_uses_Russian_roulette = np.int32(0)
-        f.Intensity_Russian_roulette_zeta_min = np.float32(0.0)
-        f.limited_intensity_contributions = np.int32(0)
-        f.max_intensity_contribution = np.float32(0.0)
+        f.Intensity_uses_hyrbid_phase_functions = np.int32(1 if useHybridPhaseFunsForIntenCalcs else 0)  # (sic) :1582-1589
+        f.Hybrid_phase_function_width = np.float32(hybridPhaseFunWidth if useHybridPhaseFunsForIntenCalcs else 0.0)
+        f.Intensity_uses_Russian_roulette = np.int32(1 if useRussianRouletteForIntensity else 0)
+        f.Intensity_Russian_roulette_zeta_min = np.float32(zetaMin if useRussianRouletteForIntensity else 0.0)
+        f.limited_intensity_contributions = np.int32(1 if limitIntensityContributions else 0)
+        f.max_intensity_contribution = np.float32(maxIntensityContribution if limitIntensityContributions else 0.0)
         f.Cpu_time_total = np.float32(cpuTimeTotal)
         f.Cpu_time_setup = np.float32(cpuTimeSetup)
         f.Number_of_processors_used = np.int32(numProcs)
@@ -191,6 +193,12 @@ def writeResults_netcdf(outputFileName, domainFileName, stats, xPosition, yPosit
         if reportVolumeAbsorption:
             f.createVariable("absorbedVolume", "f", ("z", "y", "x"))[:] = np.asarray(stats["absorbedVolume"]).transpose(2, 1, 0)
             f.createVariable("absorbedVolume_StdErr", "f", ("z", "y", "x"))[:] = np.asarray(stats["absorbedVolume_StdErr"]).transpose(2, 1, 0)
+        if intensityMus is not None and "intensity" in stats:  # :1666-1676, :1767-1778 (Fortran dims x, y, direction)
+            f.createDimension("direction", len(intensityMus))
+            f.createVariable("intensityMus", "f", ("direction",))[:] = np.asarray(intensityMus, np.float32)
+            f.createVariable("intensityPhis", "f", ("direction",))[:] = np.asarray(intensityPhis, np.float32)
+            f.createVariable("intensity", "f", ("direction", "y", "x"))[:] = np.asarray(stats["intensity"]).transpose(2, 1, 0)
+            f.createVariable("intensity_StdErr", "f", ("direction", "y", "x"))[:] = np.asarray(stats["intensity_StdErr"]).transpose(2, 1, 0)
     finally:
         f.close()
     return outputFileName

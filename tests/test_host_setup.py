@@ -117,3 +117,25 @@ def test_error_behaviour_mirrors_reference(M):
         dom.addOpticalComponent("c", np.ones((1, 1, 2)), np.ones((1, 1, 2)), 2 * np.ones((1, 1, 2), np.int32), tbl)
     with pytest.raises(M.McbratError, match="singleScatteringAlbedo"):
         dom.addOpticalComponent("c", np.ones((1, 1, 2)), 1.5 * np.ones((1, 1, 2)), np.ones((1, 1, 2), np.int32), tbl)
+
+
+def test_forward_tables_and_hybrid_phase_functions_match_oracle(M):
+    """tabulateForwardPhaseFunctions (opticalProperties.f95:1872-1935) and computeHybridPhaseFunctions
+    (:1937-2009): the product's own host routines against the oracle's restatement."""
+    from mcbrat3d_amd.phase import computeHybridPhaseFunctions
+    n = 1801
+    angles = O.forward_angles(n)
+    coef = cases.hg_legendre(0.95, 300)
+    got = M.new_PhaseFunction(coef).forward_table(n)
+    ref = O.phase_values_legendre(coef, angles)
+    assert np.allclose(got, ref, rtol=2e-6, atol=1e-6 * ref.max())  # same sums, libm cos vs cosf association
+    a, v = cases.tabulated_two_lobe()
+    got_t = M.new_PhaseFunction(a, v).forward_table(n)
+    ref_t = O.phase_values_tabulated(a, O.normalize_phase_function(a, v), angles)
+    assert np.allclose(got_t, ref_t, rtol=1e-5, atol=1e-6)
+    hyb = computeHybridPhaseFunctions(np.stack([ref, ref_t * 0 + ref]), 7.0)
+    hyb_ref = O.hybrid_phase_functions(angles, np.stack([ref, ref]), 7.0)
+    assert np.allclose(hyb, hyb_ref, rtol=1e-5)
+    assert hyb[0, 0] < ref[0] and np.array_equal(hyb[0, 400:], ref[400:])
+    iso = M.new_PhaseFunction(np.zeros(0, np.float32)).forward_table(11)
+    assert np.all(iso == 0.5)
