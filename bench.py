@@ -208,7 +208,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get(a.workload, {}).get("hbm_bytes_per_launch")
+                rec = json.load(f).get(a.workload, {})
+            if rec.get("hbm_bytes_per_launch") is not None:  # counters were collected on launches of photons_per_launch photons
+                traffic = rec["hbm_bytes_per_launch"] * per_step / rec.get("photons_per_launch", per_step)
         out = {
             "metric": "photons/sec", "value": world * per_step * a.steps / elapsed, "unit": "photons/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
