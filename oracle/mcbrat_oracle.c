@@ -627,13 +627,33 @@ static float compute_scattering_angle(float u, const float *tbl, int n) { /* :15
   return tbl[n - 1];
 }
 
+/* (cos, sin) of 2 pi u, u in [0,1]: the expression the HIP kernel evaluates (sincos_2pi), term for term */
+static void sincos_2pi(float u, float *c, float *s) {
+  const float q = rintf(4.0f * u);
+  const float r = (u - 0.25f * q) * 6.28318548202514648f;
+  const float z = r * r;
+  const float cc = fmaf(z, fmaf(z, fmaf(z, fmaf(z, 2.43904487962774090654e-5f, -1.38867637746099294692e-3f),
+                                        4.16666233237390631894e-2f), -0.499999997251031003120f), 1.0f);
+  const float ss = fmaf(r * z, fmaf(z, fmaf(z, fmaf(z, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f),
+                                            8.3333293858894631756e-3f), -0.166666666416265235595f), r);
+  const int qi = (int)q & 3;
+  *c = qi == 0 ? cc : (qi == 1 ? -ss : (qi == 2 ? -cc : ss));
+  *s = qi == 0 ? ss : (qi == 1 ? cc : (qi == 2 ? -ss : -cc));
+}
+
 static void next_direct(orc_rng *R, float scatteringCosine, float S[3]) { /* :1921-1948 */
   float D = 2.0f, AX = 0.f, AY = 0.f, B;
-  for (uint32_t k = 0; D > 1.0f; k++) { /* Philox slots: round 0 = block 0 elems 2,3; round k>=1 = block 2+(k-1)/2 */
-    const uint32_t blk = k == 0 ? 0u : 2u + ((k - 1) >> 1), el = k == 0 ? 2u : 2u * ((k - 1) & 1u);
-    AX = 1.0f - 2.0f * draw(R, blk, el);
-    AY = 1.0f - 2.0f * draw(R, blk, el + 1);
-    D = AX * AX + AY * AY;
+  if (R->mode == 1) {
+    /* Philox mode (what the HIP kernel does): the uniformly distributed unit vector (AX, AY)/sqrt(D) of the
+     * rejection loop below is (cos, sin) of a uniform azimuth, taken from ONE number: slot Y of the leg's block */
+    sincos_2pi(draw(R, 0, 2), &AX, &AY);
+    D = 1.0f;
+  } else {
+    while (D > 1.0f) { /* MT mode: the reference's loop and draw order */
+      AX = 1.0f - 2.0f * draw(R, 0, 0);
+      AY = 1.0f - 2.0f * draw(R, 0, 0);
+      D = AX * AX + AY * AY;
+    }
   }
   B = sqrtf((1.0f - scatteringCosine * scatteringCosine) / D);
   AX = AX * B;
@@ -930,7 +950,7 @@ int64_t orc_compute_rt_intensity(const orc_problem *P, const orc_source *S, orc_
     int fate = -1;
     float fateWeight = 0.0f;
     for (;;) { /* scatteringLoop :548 */
-      if (R->mode == 1) philox_next_event(R); /* event e: block 0 = [tau, X, Y, Z], block 1 = [component, roulette, -, -] */
+      if (R->mode == 1) philox_next_event(R); /* event e: block 0 = [tau, X, Y, Z], block 1 = [-, roulette, -, -]; scattering angle = X, azimuth = Y, component = Z */
       float u = draw(R, 0, 0);
       float tauToTravel = -logf(u > FLT_MIN ? u : FLT_MIN); /* :554 */
       cnt.legs++;
@@ -1003,7 +1023,7 @@ int64_t orc_compute_rt_intensity(const orc_problem *P, const orc_source *S, orc_
         double tbl[ORC_MAX_COMPONENTS + 1];
         tbl[0] = 0.0;
         for (int c = 1; c <= nc; c++) tbl[c] = P->cumExt[IDX4(P, xIndex, yIndex, zIndex, c)];
-        int component = orc_find_index_mixed(draw(R, 1, 0), tbl, nc + 1, 0); /* block 1 elem 0 */ /* :759-760 */
+        int component = orc_find_index_mixed(draw(R, 0, 3), tbl, nc + 1, 0); /* slot Z of the leg's block */ /* :759-760 */
         if (component < 1) component = 1;
         if (component > nc) component = nc;
         float ssa = (float)P->ssa[IDX4(P, xIndex, yIndex, zIndex, component)]; /* :764 */
