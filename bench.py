@@ -94,10 +94,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="i3rcStepCloud", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-photons-per-core", type=int, default=4000000)
+    ap.add_argument("--cpu-photons-per-core", type=int, default=8000000)
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parity-photons", type=int, default=100000000)
+    ap.add_argument("--parity-photons", type=int, default=400000000)
     ap.add_argument("--event-threshold", type=int, default=0,
                     help="0 = let the library time trial launches (default); >0 fixes it (profiling runs)")
     ap.add_argument("--pipeline", action="store_true",
