@@ -53,6 +53,7 @@ struct mcbrat_ctx {
   uint16_t *dPfi = nullptr;
   // brick layout (see mcbrat_kernels.hip locate_cell)
   uint32_t *dBrickTable = nullptr;
+  float *dLayerExt = nullptr;  // [nz] extinction of a horizontally uniform layer, -1 otherwise
   float *dExtB = nullptr, *dCumB = nullptr, *dSsaB = nullptr, *dBgExt = nullptr, *dBgCum = nullptr, *dBgSsa = nullptr;
   uint16_t *dPfiB = nullptr, *dBgPfi = nullptr;
   int nbx = 0, nby = 0, nbz = 0;
@@ -230,7 +231,7 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
                  const std::vector<uint16_t> &pf, int nc) {
   const int nx = c->nx, ny = c->ny, nz = c->nz;
   const size_t ncol = (size_t)nx * ny, nvox = ncol * nz;
-  std::vector<float> bgExt(nz), bgCum((size_t)nc * nz), bgSsa((size_t)nc * nz);
+  std::vector<float> bgExt(nz), bgCum((size_t)nc * nz), bgSsa((size_t)nc * nz), layerExt(nz);
   std::vector<uint16_t> bgPfi((size_t)nc * nz);
   std::vector<float> layer(ncol);
   for (int k = 0; k < nz; ++k) {
@@ -245,6 +246,7 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
       i = j;
     }
     bgExt[k] = best;
+    layerExt[k] = bestRun == ncol ? best : -1.0f;  // a layer of one extinction value needs no gather in the walk
     size_t rep = ncol * k;
     while (e[rep] != best) ++rep;  // a representative background cell of this layer
     for (int q = 0; q < nc; ++q) {
@@ -253,6 +255,7 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
       bgPfi[(size_t)q * nz + k] = pf[(size_t)q * nvox + rep];
     }
   }
+  if (upload(c, &c->dLayerExt, layerExt.data(), layerExt.size())) return 1;
   auto isBackground = [&](size_t v, int k) {
     if (e[v] != bgExt[k]) return false;
     for (int q = 0; q < nc; ++q)
@@ -338,6 +341,7 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
     p.bgExt = c->dBgExt; p.bgCum = c->dBgCum; p.bgSsa = c->dBgSsa; p.bgPfi = c->dBgPfi;
   } else {
     p.ext = c->dExt; p.cum = c->dCum; p.ssa = c->dSsa; p.pfi = c->dPfi;
+    p.bgExt = c->dLayerExt;  // dense layout: the per-layer slot holds the uniform-layer shortcut
   }
   p.albedo = c->albedo;
   p.tables = c->dTables;
@@ -376,7 +380,7 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
   const size_t slab = sizeof(long long) * slabStride + 16;
   L.priv = c->privMode != 0 && slab <= kPrivSlabLimit;
   L.brick = use_bricks(c);
-  const size_t bg = L.brick ? sizeof(float) * (size_t)((c->nz + 3) & ~3) : 0;
+  const size_t bg = sizeof(float) * (size_t)((c->nz + 3) & ~3);  // per-layer extinction (background / uniform layers)
   L.tblLds = tbl <= kTableLdsLimit && edges + bg + tbl + (L.priv ? slab : 0) <= kLdsBudget;
   if (L.priv && edges + bg + slab + (L.tblLds ? tbl : 0) > kLdsBudget) L.priv = false;
   // small domains: the optical grid itself (ext + per-component cum, ssa, phase index) goes to LDS when it fits
@@ -389,7 +393,7 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
 }
 
 size_t plan_launch_lds(const mcbrat_ctx *c, const LaunchPlan &L) {
-  return sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3) + (L.brick ? sizeof(float) * (size_t)((c->nz + 3) & ~3) : 0) +
+  return sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3) + sizeof(float) * (size_t)((c->nz + 3) & ~3) +
          (L.tblLds ? sizeof(float) * (size_t)c->tblTotalFloats : 0);
 }
 
@@ -520,7 +524,7 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   (void)sync_all(c);
   void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF,
                   c->dEventCounters, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
-                  c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi};
+                  c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (mcbrat_ctx::Lane &L : c->lane) {
     void *lb[] = {L.dCounter, L.dSlabs, L.dColVals, L.dScalVals};

@@ -12,6 +12,7 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--thr", type=int, default=0)
 ap.add_argument("--priv", type=int, default=-1)
 ap.add_argument("--block", type=int, default=-1)
+ap.add_argument("--brick", type=int, default=-1)
 a = ap.parse_args()
 import mcbrat3d_amd as M  # noqa: E402
 from mcbrat3d_amd.integrator import new_RandomNumberSequence  # noqa: E402
@@ -23,7 +24,7 @@ else:
 dom = cases.product_domain(case)
 integ = M.new_Integrator(dom)
 integ.specifyParameters(minInverseTableSize=10001)
-integ.setTuning(eventThreshold=a.thr, privateTallies=a.priv, blockSize=a.block)
+integ.setTuning(eventThreshold=a.thr, privateTallies=a.priv, blockSize=a.block, brickLayout=a.brick)
 photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
 rng = new_RandomNumberSequence(10)
 for i in range(a.steps):
