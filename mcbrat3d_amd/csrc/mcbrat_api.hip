@@ -53,6 +53,7 @@ struct mcbrat_ctx {
   uint16_t *dPfi = nullptr;
   // brick layout (see mcbrat_kernels.hip locate_cell)
   uint32_t *dBrickTable = nullptr;
+  uint32_t *dRec = nullptr;    // packed collision record per cell (nc <= 2), see DevParams::rec
   float *dLayerExt = nullptr;  // [nz] extinction of a horizontally uniform layer, -1 otherwise
   float *dExtB = nullptr, *dCumB = nullptr, *dSsaB = nullptr, *dBgExt = nullptr, *dBgCum = nullptr, *dBgSsa = nullptr;
   uint16_t *dPfiB = nullptr, *dBgPfi = nullptr;
@@ -342,6 +343,7 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   } else {
     p.ext = c->dExt; p.cum = c->dCum; p.ssa = c->dSsa; p.pfi = c->dPfi;
     p.bgExt = c->dLayerExt;  // dense layout: the per-layer slot holds the uniform-layer shortcut
+    p.rec = reinterpret_cast<const uint4 *>(c->dRec);
   }
   p.albedo = c->albedo;
   p.tables = c->dTables;
@@ -524,7 +526,7 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   (void)sync_all(c);
   void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF,
                   c->dEventCounters, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
-                  c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt};
+                  c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (mcbrat_ctx::Lane &L : c->lane) {
     void *lb[] = {L.dCounter, L.dSlabs, L.dColVals, L.dScalVals};
@@ -611,6 +613,18 @@ int mcbrat_set_optics(mcbrat_ctx *c, int32_t nc, const double *totalExt, const d
   if (upload(c, &c->dExt, e.data(), e.size()) || upload(c, &c->dCum, cu.data(), cu.size()) ||
       upload(c, &c->dSsa, s.data(), s.size()) || upload(c, &c->dPfi, pf.data(), pf.size()))
     return 1;
+  if (c->dRec) { (void)hipFree(c->dRec); c->dRec = nullptr; }
+  if (nc <= 2) {
+    std::vector<uint32_t> rec(4 * nvox);
+    for (size_t v = 0; v < nvox; ++v) {
+      std::memcpy(&rec[4 * v + 0], &cu[v], 4);
+      std::memcpy(&rec[4 * v + 1], &s[v], 4);
+      const float s1 = nc > 1 ? s[nvox + v] : 0.0f;
+      std::memcpy(&rec[4 * v + 2], &s1, 4);
+      rec[4 * v + 3] = (uint32_t)pf[v] | ((uint32_t)(nc > 1 ? pf[nvox + v] : 0) << 16);
+    }
+    if (upload(c, &c->dRec, rec.data(), rec.size())) return 1;
+  }
   c->bricksBuilt = false;
   if (build_bricks(c, e, cu, s, pf, nc)) return 1;
   c->nc = nc;

@@ -27,6 +27,7 @@ struct DevParams {
   const float *cum;               // [nc][nvox] (read only when nc > 1)
   const float *ssa;               // [nc][nvox]
   const uint16_t *pfi;            // [nc][nvox] 0-based entry
+  const uint4 *rec;               // dense layout, nc <= 2: per cell {cum[0], ssa[0], ssa[1], pfi[0] | pfi[1] << 16}, else null
   float albedo;
   // brick layout of the optics (large, mostly-background domains): ext/cum/ssa/pfi then hold the
   // STORED bricks only (64 cells each, [component][nStored]); background cells use bg* [component][nz]
