@@ -99,7 +99,8 @@ program mcbrat_driver
     allocate(forwardTable(max(nPhaseIntervals, 9001), 1))
     call forwardTableLegendre(legendreCoefficients, forwardTable(:, 1), ierr); call check("forwardTableLegendre")
     call specifyIntensity(mcIntegrator, pack(intensityMus, abs(intensityMus) > 0.), pack(intensityPhis, abs(intensityMus) > 0.), &
-                          useRussianRouletteForIntensity, zetaMin, .false., numOrdersOrigPhaseFunIntenCalcs, ierr)
+                          useRussianRouletteForIntensity, zetaMin, .false., numOrdersOrigPhaseFunIntenCalcs, &
+                          limitIntensityContributions, maxIntensityContribution, ierr)
     call check("specifyParameters")
     call setForwardTable(mcIntegrator, 1, forwardTable, forwardTable, ierr); call check("setForwardTable")
   end if

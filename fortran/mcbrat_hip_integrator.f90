@@ -318,17 +318,20 @@ contains
   end subroutine getMoments
   ! specifyParameters, intensity keywords (:1046-1292): directions and variance-reduction choices
   subroutine specifyIntensity(this, intensityMus, intensityPhis, useRussianRouletteForIntensity, zetaMin, &
-                              useHybridPhaseFunsForIntenCalcs, numOrdersOrigPhaseFunIntenCalcs, ierr)
+                              useHybridPhaseFunsForIntenCalcs, numOrdersOrigPhaseFunIntenCalcs, &
+                              limitIntensityContributions, maxIntensityContribution, ierr)
     type(integrator),   intent(inout) :: this
     real, dimension(:), intent(in)    :: intensityMus, intensityPhis
-    logical,            intent(in)    :: useRussianRouletteForIntensity, useHybridPhaseFunsForIntenCalcs
-    real,               intent(in)    :: zetaMin
+    logical,            intent(in)    :: useRussianRouletteForIntensity, useHybridPhaseFunsForIntenCalcs, &
+                                         limitIntensityContributions
+    real,               intent(in)    :: zetaMin, maxIntensityContribution
     integer,            intent(in)    :: numOrdersOrigPhaseFunIntenCalcs
     integer,            intent(out)   :: ierr
     ierr = mcbrat_specify_intensity(this%ctx, int(size(intensityMus), c_int32_t), intensityMus, intensityPhis, &
                                     merge(1_c_int32_t, 0_c_int32_t, useRussianRouletteForIntensity), zetaMin, &
                                     merge(1_c_int32_t, 0_c_int32_t, useHybridPhaseFunsForIntenCalcs), &
-                                    int(numOrdersOrigPhaseFunIntenCalcs, c_int32_t), 0_c_int32_t, huge(1.0))
+                                    int(numOrdersOrigPhaseFunIntenCalcs, c_int32_t), &
+                                    merge(1_c_int32_t, 0_c_int32_t, limitIntensityContributions), maxIntensityContribution)
   end subroutine specifyIntensity
   ! tabulatedPhaseFunctions(component)%values / tabulatedOrigPhaseFunctions(component)%values (nAngles, nEntries)
   subroutine setForwardTable(this, component, values, origValues, ierr)

@@ -114,9 +114,11 @@ int mcbrat_report_results(mcbrat_ctx *ctx, float *meanFluxUp, float *meanFluxDow
  * launch, surface reflection and scattering event then adds weight * phase function /
  * (4 pi |mu|) * transmission to the pixel where the view ray leaves the domain.
  * Roulette (Iwabuchi 2006, the driver's default) is accepted for upward directions only: for
- * mu < 0 the reference restarts its walk below the surface.  limitIntensityContributions (off by
- * default) is not supported.  Changing the number of directions changes mcbrat_moments_length():
- * a caller-bound moment buffer must be bound again. */
+ * mu < 0 the reference restarts its walk below the surface.  With limitIntensityContributions each
+ * local estimate is clipped at maxIntensityContribution and the clipped excess of a (component,
+ * direction) is spread over the pixels in proportion to that component's radiance field at the end
+ * of the batch (:294-320, :1815-1826).  Changing the number of directions changes
+ * mcbrat_moments_length(): a caller-bound moment buffer must be bound again. */
 int mcbrat_specify_intensity(mcbrat_ctx *ctx, int32_t nDirections, const float *intensityMus,
                              const float *intensityPhisDeg, int32_t useRussianRouletteForIntensity,
                              float zetaMin, int32_t useHybridPhaseFunsForIntenCalcs,

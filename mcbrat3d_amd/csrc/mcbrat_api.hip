@@ -82,8 +82,8 @@ struct mcbrat_ctx {
   std::vector<int> fwdNAngles, fwdNEntries;
   int fwdOffset[MCBRAT_MAX_COMPONENTS] = {0};
   bool fwdDirty = true;
-  int useHybrid = 0, numOrdersOrig = 0, useRRIntensity = 0;
-  float zetaMin = 0.3f;
+  int useHybrid = 0, numOrdersOrig = 0, useRRIntensity = 0, limitContrib = 0;
+  float zetaMin = 0.3f, maxContrib = FLT_MAX;
   // parameters
   float albedo = 0.f;
   int useRR = 1;
@@ -359,6 +359,7 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.dirData = c->dDirData; p.fwdTables = c->dFwd; p.fwdOrig = c->dFwdOrig;
   for (int k = 0; k < c->nc && c->nDir > 0; ++k) { p.fwdOffset[k] = c->fwdOffset[k]; p.fwdNAngles[k] = c->fwdNAngles[k]; }
   p.useHybrid = c->useHybrid; p.numOrdersOrig = c->numOrdersOrig; p.useRRIntensity = c->useRRIntensity; p.zetaMin = c->zetaMin;
+  p.limitContrib = c->limitContrib; p.maxContrib = c->maxContrib;
   p.counter = c->L().dCounter;
   p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
   p.launchThreshold = std::max(1, std::min(64, c->launchThreshold));
@@ -785,8 +786,8 @@ int mcbrat_specify_intensity(mcbrat_ctx *c, int32_t nDirections, const float *mu
     if (std::fabs(mus[i]) < FLT_MIN) return fail(c, "specifyParameters: intensityMus can't be 0 (directly sideways)");
     if (phisDeg[i] < 0.f || phisDeg[i] > 360.f) return fail(c, "specifyParameters: intensityPhis must be between 0 and 360");
   }
-  if (limitIntensityContributions && maxIntensityContribution < FLT_MAX)
-    return fail(c, "specifyParameters: limitIntensityContributions is not supported (off by default in the reference's driver).");
+  if (limitIntensityContributions && !(maxIntensityContribution > 0.f))
+    return fail(c, "specifyParameters: maxIntensityContribution must be > 0");
   if (zetaMin < 0.f) return fail(c, "specifyParameters: zetaMin must be >= 0.");
   if (numOrdersOrigPhaseFunIntenCalcs < 0) return fail(c, "specifyParameters: numOrdersOrigPhaseFunIntenCalcs must be >= 0");
   if (useRussianRouletteForIntensity)
@@ -806,6 +807,11 @@ int mcbrat_specify_intensity(mcbrat_ctx *c, int32_t nDirections, const float *mu
     d[3] = (4.0f * kPi) * std::fabs(d[2]);
     for (int a = 0; a < 3; ++a) d[4 + a] = std::fabs(d[a]) >= 2.0f * FLT_MIN ? 1.0f / d[a] : 0.0f;
   }
+  const int limit = (limitIntensityContributions && maxIntensityContribution < FLT_MAX) ? 1 : 0;
+  if (limit != c->limitContrib)  // the batch slabs change length
+    for (mcbrat_ctx::Lane &L : c->lane) L.slabCapacity = L.finishCapacity = 0;
+  c->limitContrib = limit;
+  c->maxContrib = maxIntensityContribution;
   if (nDirections != c->nDir) {  // the moment arrays change length: start them afresh
     if (c->dMomentsOwned) { (void)hipFree(c->dMomentsOwned); c->dMomentsOwned = nullptr; }
     c->dMoments = nullptr;
@@ -909,7 +915,9 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     c->cur = 0;
   }
   const size_t ncol = (size_t)c->nx * c->ny, nvox = ncol * c->nz;
-  const size_t slabStride = 2 * ncol + nvox + (size_t)c->nDir * ncol;  // [fluxUp | fluxDown | volume | intensity per direction]
+  // [fluxUp | fluxDown | volume | intensity per direction | (limitIntensityContributions:) intensity by component, excess]
+  const size_t slabStride = 2 * ncol + nvox + (size_t)c->nDir * ncol +
+                            (c->limitContrib ? (size_t)(c->nc + 1) * c->nDir * (ncol + 1) : 0);
   // batches in flight: bounded by a memory budget (slabs are 8 B per tally bin per batch)
   size_t inFlight = std::max<size_t>(1, (size_t)(4ull << 30) / (slabStride * sizeof(long long)));
   if (c->maxBatchesInFlight > 0) inFlight = std::min<size_t>(inFlight, (size_t)c->maxBatchesInFlight);
@@ -970,13 +978,15 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     if (c->lastDone && c->lastDone != c->L().evDone) HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->lastDone, 0));
     if (c->externalPending) { HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->evExternal, 0)); c->externalPending = false; }
     FinishParams f;
-    f.nx = c->nx; f.ny = c->ny; f.nz = c->nz; f.nBatches = nb; f.xyRegular = c->xyRegular; f.nDir = c->nDir;
+    f.nx = c->nx; f.ny = c->ny; f.nz = c->nz; f.nBatches = nb; f.xyRegular = c->xyRegular; f.nDir = c->nDir; f.nc = c->nc; f.limitContrib = c->limitContrib;
     f.ppb = p.ppb; f.total = p.total; f.slabStride = slabStride;
     f.slabs = c->L().dSlabs; f.relArea = c->dRelArea; f.ze = c->dEdges + (c->nx + 1) + (c->ny + 1);
     f.colVals = c->L().dColVals; f.scalVals = c->L().dScalVals; f.moments = c->dMoments; f.last = c->dLast;
     hipLaunchKernelGGL(finish_columns, dim3((unsigned)((ncol * (size_t)nb + 255) / 256)), dim3(256), 0, c->L().stream, f);
     hipLaunchKernelGGL(finish_column_moments, dim3((unsigned)((3 * ncol + 255) / 256)), dim3(256), 0, c->L().stream, f);
     hipLaunchKernelGGL(finish_volume, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, c->L().stream, f);
+    if (c->nDir > 0 && c->limitContrib)
+      hipLaunchKernelGGL(finish_excess, dim3(c->nDir, nb), dim3(256), 0, c->L().stream, f);
     if (c->nDir > 0)
       hipLaunchKernelGGL(finish_intensity, dim3((unsigned)((ncol * (size_t)c->nDir + 255) / 256)), dim3(256), 0, c->L().stream, f);
     hipLaunchKernelGGL(finish_reduce, dim3(3 + c->nz, nb), dim3(256), 0, c->L().stream, f);

@@ -62,6 +62,8 @@ struct DevParams {
   int useHybrid, numOrdersOrig;   // original tables up to this scattering order, hybrid ones beyond
   int useRRIntensity;             // Iwabuchi (2006) roulette on the local estimates
   float zetaMin;
+  int limitContrib;               // limitIntensityContributions: clip each local estimate, redistribute the excess (:294-320, :1815-1826)
+  float maxContrib;
   // work
   unsigned long long *counter;    // next global photon index
   unsigned long long total;       // photons in this launch
