@@ -146,7 +146,8 @@ int mcbrat_report_intensity(mcbrat_ctx *ctx, float *meanIntensity, float *intens
  * wants to all-reduce it with RCCL binds its own device buffer. */
 int64_t mcbrat_moments_length(const mcbrat_ctx *ctx);
 int mcbrat_bind_moments(mcbrat_ctx *ctx, double *deviceBuffer); /* NULL: library-owned */
-int mcbrat_reset_moments(mcbrat_ctx *ctx);
+int mcbrat_reset_moments(mcbrat_ctx *ctx); /* stream-ordered: enqueued before whatever the context does next; a caller
+                                              that reads a bound buffer itself calls mcbrat_synchronize first */
 int mcbrat_get_moments(mcbrat_ctx *ctx, double *hostBuffer);
 
 /* Measurement: HIP-event duration of the tracing kernel(s) of the last

@@ -21,6 +21,8 @@ struct DevParams {
   double x0, y0, z0, xMax, yMax, zMax, Lx, Ly;
   double zSurf;                   // z0 + spacing(z0): where a reflected photon restarts (:633)
   double invDX, invDY;            // 1/deltaX, 1/deltaY when xyRegular
+  int xyRegularWalk, zRegularWalk; // equally spaced axes: the walk steps their face distances by dXf|1/dir| etc.
+  float dXf, dYf, dZf;
   const double *edges;            // [xe(nx+1) | ye(ny+1) | ze(nz+1)]
   // optics (set_optics), float copies of the reference's real(8) arrays
   const float *ext;               // [nvox]
