@@ -982,7 +982,13 @@ int64_t orc_compute_rt_intensity(const orc_problem *P, const orc_source *S, orc_
         float wBefore = photonWeight;
         photonWeight = (float)((double)photonWeight * albedo); /* :673 */
         if (photonWeight <= FLT_MIN) { cnt.surfaceAbsorbed++; fate = 1; fateWeight = wBefore; break; }
-        make_direction_cosines(mu, phi, dir);
+        if (R->mode == 1) { /* Philox mode: cos / sin of 2 pi Y by the kernel's expression (sincos_2pi), as in next_direct */
+          float sinTheta = sqrtf(1.0f - mu * mu), c, s;
+          sincos_2pi(draw(R, 0, 2), &c, &s);
+          dir[0] = sinTheta * c; dir[1] = sinTheta * s; dir[2] = mu;
+        } else {
+          make_direction_cosines(mu, phi, dir);
+        }
         if (nDir > 0) { /* :680-702 */
           intensity_contribution(P, I, R, photonWeight, xPos, yPos, zPos, xIndex, yIndex, zIndex, dir, 0,
                                  scatteringOrder, contributions, xIndexF, yIndexF, intensityExcess);
