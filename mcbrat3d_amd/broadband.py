@@ -44,22 +44,17 @@ def emitted_flux_cdf(fluxes):
     return c, total
 
 
-def frequency_distribution(cdf, totalPhotons, seed=10, chunk=1 << 24):
-    """getFrequencyDistr: one uniform per photon picks its wavelength (smallest i with
-    U <= CDF(i), findCDFIndex).  The reference draws them one by one from its MT stream on every
-    rank; here they come in chunks from a counter-based generator, which gives the same
-    multinomial law."""
+def frequency_distribution(cdf, totalPhotons, seed=10):
+    """getFrequencyDistr: the reference draws one uniform per photon from its MT stream (on every rank) and counts
+    the photons that fall into each interval of the power CDF (smallest i with U <= CDF(i), findCDFIndex) -- an
+    O(numPhotons) host loop, 10^9 draws for a production run.  The counts are one sample of
+    Multinomial(totalPhotons, diff(CDF)); here that sample is drawn directly (conditional binomials, O(numLambda))
+    from a counter-based generator keyed by the seed."""
     cdf = np.asarray(cdf, np.float64)
-    counts = np.zeros(len(cdf), np.int64)
+    p = np.diff(np.concatenate([[0.0], cdf]))
+    p = np.clip(p, 0.0, None)
     rng = np.random.Generator(np.random.Philox(key=int(seed)))
-    left = int(totalPhotons)
-    while left > 0:
-        n = min(left, chunk)
-        u = rng.random(n, dtype=np.float32).astype(np.float64)
-        idx = np.searchsorted(cdf, u, side="left")  # smallest i with u <= cdf[i]
-        counts += np.bincount(np.minimum(idx, len(cdf) - 1), minlength=len(cdf))
-        left -= n
-    return counts
+    return rng.multinomial(int(totalPhotons), p / p.sum()).astype(np.int64)
 
 
 def run_thermal(integrator, domains, surfaceTemp, numPhotonsPerBatch, numBatches, randomNumbers, seed=10):
