@@ -29,7 +29,7 @@ def main():
     a = ap.parse_args()
     import mcbrat3d_amd as M
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
-    case = cases.step_cloud(a.ssa) if a.case == "step" else cases.landsat_like(ssa_cloud=a.ssa)
+    case = cases.step_cloud(a.ssa) if a.case == "step" else (cases.radar_like() if a.case == "radar" else cases.landsat_like(ssa_cloud=a.ssa))
     mu0, phi0 = (1.0, 0.0) if a.case == "step" else (0.5, 30.0)
     t0 = time.time()
     dom = cases.product_domain(case)
