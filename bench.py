@@ -117,7 +117,20 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when its communicator comes up; the contract is ONE JSON line there,
+        # so file descriptor 1 points at stderr until the first collective is through
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the photon-tracing path has no CPU fallback")
     torch.cuda.set_device(local_rank)
