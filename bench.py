@@ -34,8 +34,11 @@ from tests import cases  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 WORKLOADS = {
-    "i3rcStepCloud": dict(make=lambda: cases.step_cloud(ssa=0.99), mu0=1.0, phi0=0.0, ppb=100000, batches=100),
-    "landsatLike128": dict(make=lambda: cases.landsat_like(), mu0=0.5, phi0=30.0, ppb=1000000, batches=100),
+    # cpu: photons per host core of the cpu_baseline sample (about 20 s of oracle time), parity: photons of the GPU parity run
+    "i3rcStepCloud": dict(make=lambda: cases.step_cloud(ssa=0.99), mu0=1.0, phi0=0.0, ppb=100000, batches=100,
+                          cpu=8000000, parity=400000000),
+    "landsatLike128": dict(make=lambda: cases.landsat_like(), mu0=0.5, phi0=30.0, ppb=1000000, batches=100,
+                           cpu=2000000, parity=100000000),
 }
 
 
@@ -94,10 +97,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="i3rcStepCloud", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-photons-per-core", type=int, default=8000000)
+    ap.add_argument("--cpu-photons-per-core", type=int, default=0, help="0 = the workload's default")
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parity-photons", type=int, default=400000000)
+    ap.add_argument("--parity-photons", type=int, default=0, help="0 = the workload's default")
     ap.add_argument("--event-threshold", type=int, default=0,
                     help="0 = let the library time trial launches (default); >0 fixes it (profiling runs)")
     ap.add_argument("--pipeline", action="store_true",
@@ -141,6 +144,8 @@ def main():
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
 
     w = WORKLOADS[a.workload]
+    a.cpu_photons_per_core = a.cpu_photons_per_core or w["cpu"]
+    a.parity_photons = a.parity_photons or w["parity"]
     case = w["make"]()
     dom = cases.product_domain(case)
     nx, ny, nz = dom.numX, dom.numY, dom.numZ
