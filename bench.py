@@ -239,7 +239,7 @@ def main():
             "config": {"workload": "%s %dx%dx%d, %d photons/GPU/step as %d batches x %d, omega0=0.99 HG g=0.85 mu0=%g"
                        % (a.workload, nx, ny, nz, per_step, nb, ppb, w["mu0"]),
                        "photons_per_step_per_gpu": per_step, "parallelism": "photon batches sharded over %d GPU(s)" % world,
-                       "pipelined_steps": bool(a.pipeline)},
+                       "pipelined_steps": bool(a.pipeline), "event_threshold": integ.eventThreshold()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_photon": bpp, "kernel": "trace_kernel", "kernel_ms_per_launch": launch_ms,

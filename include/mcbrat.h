@@ -184,6 +184,9 @@ int mcbrat_set_tuning(mcbrat_ctx *ctx, int32_t blocksPerCU, int32_t eventThresho
                       int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold,
                       int32_t brickLayout);
 
+/* The event threshold in use (after the first call of a domain: the one chosen by the trial launches). */
+int mcbrat_get_event_threshold(const mcbrat_ctx *ctx);
+
 /* Parity/debug: trace n photons (ids firstPhotonId..) and record what became
  * of each one.  Tallies and moments of the context are left untouched. */
 int mcbrat_trace_fates(mcbrat_ctx *ctx, uint64_t seed, uint64_t firstPhotonId, int64_t n,

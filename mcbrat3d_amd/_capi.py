@@ -62,6 +62,7 @@ SYMBOLS = {
     "mcbrat_forward_table_legendre": (C.c_int, [_i32, _vp, _i32, _vp]),
     "mcbrat_forward_table_tabulated": (C.c_int, [_i32, _vp, _vp, _i32, _vp]),
     "mcbrat_hybrid_phase_functions": (C.c_int, [_i32, _i32, _vp, _f, _vp]),
+    "mcbrat_get_event_threshold": (C.c_int, [_vp]),
     "mcbrat_set_async": (C.c_int, [_vp, _i32]),
     "mcbrat_synchronize": (C.c_int, [_vp]),
     "mcbrat_stream_wait_done": (C.c_int, [_vp, _vp]),

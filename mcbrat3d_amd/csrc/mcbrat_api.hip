@@ -853,6 +853,8 @@ int mcbrat_report_intensity(mcbrat_ctx *c, float *meanIntensity, float *intensit
   return 0;
 }
 
+int mcbrat_get_event_threshold(const mcbrat_ctx *c) { return c ? c->eventThreshold : 0; }
+
 int mcbrat_set_async(mcbrat_ctx *c, int32_t enable) {
   if (!c) return 1;
   (void)hipSetDevice(c->device);

@@ -184,6 +184,9 @@ class Integrator:
         self._check(self._lib.mcbrat_set_tuning(self._ctx, blocksPerCU, eventThreshold, maxBatchesInFlight,
                                                 privateTallies, blockSize, launchThreshold, surfaceThreshold, brickLayout))
 
+    def eventThreshold(self):
+        return int(self._lib.mcbrat_get_event_threshold(self._ctx))
+
     def setAsync(self, enable=True):
         """Let consecutive computeRadiativeTransfer / resetMoments calls overlap on the GPU (include/mcbrat.h)."""
         self._check(self._lib.mcbrat_set_async(self._ctx, int(bool(enable))))
