@@ -102,6 +102,7 @@ struct mcbrat_ctx {
   int maxBatchesInFlight = 0;  // 0: bounded by memory
   int privMode = 1;            // 1: LDS-private tallies when the slab fits, 0: always global atomics
   int blockSize = 0;           // 0: chosen by plan_launch
+  unsigned long long tuneTrialPhotons = 1ull << 24;  // MCBRAT_TUNE_PHOTONS
   int regularWalk = 1;         // equally spaced grids: incremental face distances (MCBRAT_REGULAR_WALK=0 turns it off)
   int gridLdsMode = 1;         // stage the optical grid in LDS when it fits (private-tally mode)
   bool countersOn = false;
@@ -478,9 +479,16 @@ int check_ready(mcbrat_ctx *c) {
 // Times short trial launches at a few event thresholds and keeps the fastest.  The best value
 // depends on how many voxel faces a leg crosses (step cloud ~3, 128x128x64 cloud field ~14).
 int autotune(mcbrat_ctx *c, DevParams p, unsigned long long ppb, int nBatches) {
-  const unsigned long long want = 1ull << 20;  // about four photons per resident lane
+  // about 64 photons per resident lane: with fewer the synchronised start and the drain of the launch dominate
+  // and favour too low a threshold
+  const unsigned long long want = c->tuneTrialPhotons;
   const unsigned long long total = ppb * (unsigned long long)nBatches;
-  if (total < 4 * want) { c->tuned = true; return 0; }
+  if (total < want) {
+    // too few photons for a meaningful trial: a guess by domain size (few faces per leg on small grids, many on
+    // large ones), and the trial is left for a later, larger call
+    c->eventThreshold = plan_launch(c, (size_t)p.slabStride).gridLds ? 16 : 32;
+    return 0;
+  }
   const int nb = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)nBatches, want / std::max<unsigned long long>(1, ppb)));
   p.total = std::min(want, ppb * (unsigned long long)nb);
   p.fates = nullptr; p.counters = nullptr;
@@ -519,6 +527,7 @@ mcbrat_ctx *mcbrat_create(int device) {
   mcbrat_ctx *c = new mcbrat_ctx();
   c->device = device;
   if (const char *e = getenv("MCBRAT_REGULAR_WALK")) c->regularWalk = atoi(e);
+  if (const char *e = getenv("MCBRAT_TUNE_PHOTONS")) c->tuneTrialPhotons = strtoull(e, nullptr, 10);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCUs = prop.multiProcessorCount;
   if (init_lane(c, 0) || hipEventCreateWithFlags(&c->evExternal, hipEventDisableTiming) != hipSuccess ||
