@@ -91,6 +91,41 @@ def cpu_baseline(name, photons_per_core, max_cores):
                        "(%.1f s wall)" % (photons_per_core, cores, CPU_BATCH, wall)), batches, cols, counters, total
 
 
+def secondary_workload(M, new_rng, name="landsatLike128", steps=3):
+    """Untimed extra (not the contract's metric): BASELINE.json's target is quoted on a 128x128x64 domain, so the
+    default single-GPU run also reports that workload's rate: `steps` synchronous steps of 1e8 photons after one
+    warm-up step (which also lets the library choose its event threshold)."""
+    w = WORKLOADS[name]
+    dom = cases.product_domain(w["make"]())
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=10001, useRayTracing=True, useRussianRoulette=True)
+    photons = M.new_PhotonStream(w["mu0"], w["phi0"], numberOfPhotons=10 ** 15)
+    rng = new_rng(10)
+    integ.resetMoments()
+    integ.computeRadiativeTransfer(dom, rng, photons, w["ppb"], w["batches"])
+    integ.synchronize()
+    t0, kms = time.perf_counter(), 0.0
+    for _ in range(steps):
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, rng, photons, w["ppb"], w["batches"])
+        kms += integ.lastTraceMs()
+    integ.synchronize()
+    dt = time.perf_counter() - t0
+    integ.enableCounters(True)
+    integ.computeRadiativeTransfer(dom, rng, photons, w["ppb"], 10)
+    cnt = integ.counters()
+    integ.enableCounters(False)
+    per_step = w["ppb"] * w["batches"]
+    bpp = algorithmic_bytes_per_photon(cnt, w["ppb"] * 10, len(dom.components))
+    achieved = bpp * per_step / (kms / steps * 1e-3) / 1e9
+    res = {"workload": "%s %dx%dx%d, %d photons/step" % (name, dom.numX, dom.numY, dom.numZ, per_step),
+           "value": per_step * steps / dt, "unit": "photons/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+           "kernel_ms_per_launch": kms / steps, "algorithmic_bytes_per_photon": bpp,
+           "roofline_frac": achieved / HBM_PEAK_GBS, "event_threshold": integ.eventThreshold()}
+    integ.finalize()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +135,7 @@ def main():
     ap.add_argument("--cpu-photons-per-core", type=int, default=0, help="0 = the workload's default")
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed 128x128x64 extra of the default run")
     ap.add_argument("--parity-photons", type=int, default=0, help="0 = the workload's default")
     ap.add_argument("--event-threshold", type=int, default=0,
                     help="0 = let the library time trial launches (default); >0 fixes it (profiling runs)")
@@ -269,6 +305,8 @@ def main():
                              "n_column_bins": int(zc.size),
                              "gpu_means": [float(x) for x in g], "cpu_means": [float(x) for x in m_ref],
                              "cpu_events_per_photon": {k: v / ctot for k, v in ccnt.items() if k != "draws"}}
+        if world == 1 and a.workload == "i3rcStepCloud" and not a.no_secondary:
+            out["secondary"] = secondary_workload(M, new_RandomNumberSequence)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
