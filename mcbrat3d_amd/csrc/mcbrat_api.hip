@@ -635,7 +635,8 @@ int mcbrat_set_optics(mcbrat_ctx *c, int32_t nc, const double *totalExt, const d
   if (nc <= 2) {
     std::vector<uint32_t> rec(4 * nvox);
     for (size_t v = 0; v < nvox; ++v) {
-      std::memcpy(&rec[4 * v + 0], &cu[v], 4);
+      const float c0 = nc > 1 ? cu[v] : 2.0f;  // uniform >= c0 picks the second component: never with one component
+      std::memcpy(&rec[4 * v + 0], &c0, 4);
       std::memcpy(&rec[4 * v + 1], &s[v], 4);
       const float s1 = nc > 1 ? s[nvox + v] : 0.0f;
       std::memcpy(&rec[4 * v + 2], &s1, 4);
