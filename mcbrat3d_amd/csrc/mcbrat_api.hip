@@ -922,8 +922,10 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   if (check_ready(c)) return 1;
   if (ppb < 1 || nBatches < 1) return fail(c, "computeRadiativeTransfer: Didn't process any photons.");
   if (ensure_moments(c)) return 1;
-  const bool async = c->asyncOn && !c->countersOn && !(c->autoTune && !c->tuned);
-  if (!async && sync_all(c)) return 1;
+  // the trial launches that choose the event threshold run synchronously, once, on the first call large enough
+  const bool tuneNow = c->autoTune && !c->tuned && (unsigned long long)ppb * (unsigned long long)nBatches >= c->tuneTrialPhotons;
+  const bool async = c->asyncOn && !c->countersOn;
+  if ((!async || tuneNow) && sync_all(c)) return 1;
   if (c->asyncOn) {  // rotate over the lanes
     c->cur = c->nextLane;
     c->nextLane = (c->nextLane + 1) % mcbrat_ctx::kLanes;
