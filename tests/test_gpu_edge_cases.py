@@ -170,11 +170,12 @@ def test_async_calls_overlap_and_match_synchronous_mode(M):
     dom = cases.product_domain(case)
     photons = M.new_PhotonStream(1.0, 0.0, numberOfPhotons=10 ** 12)
     out = {}
-    for mode in ("sync", "async"):
+    for mode in ("sync", "async", "async_auto"):
         integ = M.new_Integrator(dom)
         integ.specifyParameters(minInverseTableSize=9001)
-        integ.setTuning(eventThreshold=16)
-        integ.setAsync(mode == "async")
+        if mode != "async_auto":  # (default: the library picks the threshold; calls this small get its guess, 16 here)
+            integ.setTuning(eventThreshold=16)
+        integ.setAsync(mode != "sync")
         rng = new_RandomNumberSequence(SEED)
         integ.resetMoments()
         integ.computeRadiativeTransfer(dom, rng, photons, 20000, 3)   # discarded by the reset below
@@ -189,6 +190,7 @@ def test_async_calls_overlap_and_match_synchronous_mode(M):
         integ.finalize()
     ms, rs, ts, ks = out["sync"]
     ma, ra, ta, ka = out["async"]
+    assert np.array_equal(ms, out["async_auto"][0]) and out["async_auto"][2] < 1.5 * ts
     assert ms[0] == ma[0] == 39 * 50000 + 12345 and ms[1] == ma[1] == 40
     assert np.array_equal(ms, ma)
     for k in rs:
