@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--priv", type=int, nargs="*", default=[-1])
     ap.add_argument("--brick", type=int, nargs="*", default=[-1])
     ap.add_argument("--block", type=int, nargs="*", default=[-1])
+    ap.add_argument("--skip", type=int, nargs="*", default=[-1])
     a = ap.parse_args()
     import mcbrat3d_amd as M
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
@@ -38,10 +39,10 @@ def main():
     photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
     print("setup %.2fs" % (time.time() - t0), flush=True)
     import itertools
-    for bpc, priv, block, thr, lthr, sthr, brick in itertools.product(a.bpc, a.priv, a.block, a.thr, a.lthr, a.sthr, a.brick):
+    for bpc, priv, block, thr, lthr, sthr, brick, skip in itertools.product(a.bpc, a.priv, a.block, a.thr, a.lthr, a.sthr, a.brick, a.skip):
       for inflight in a.inflight:
         if True:
-            integ.setTuning(blocksPerCU=bpc, eventThreshold=thr, privateTallies=priv, blockSize=block, launchThreshold=lthr, surfaceThreshold=sthr, brickLayout=brick, maxBatchesInFlight=inflight)
+            integ.setTuning(blocksPerCU=bpc, eventThreshold=thr, privateTallies=priv, blockSize=block, launchThreshold=lthr, surfaceThreshold=sthr, brickLayout=brick, maxBatchesInFlight=inflight, layerSkip=skip)
             rates = []
             for r in range(a.reps):
                 rng = new_RandomNumberSequence(1234 + r)
@@ -54,10 +55,11 @@ def main():
                 integ.enableCounters(True)
                 integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(99), photons, a.ppb, a.batches)
                 c = integ.counters(); integ.enableCounters(False)
+                print('   per photon: legs %.2f crossings %.2f collisions %.2f' % (c['legs'] / n, c['crossings'] / n, c['collisions'] / n))
                 print('   walk iters %.4g lanes/iter %.1f | event phases %.4g lanes/phase %.1f | launch phases %.4g surf phases %.4g | walk iters per event phase %.2f' % (c['walkIterations'], c['walkLanes']/max(1,c['walkIterations']), c['eventPhases'], c['eventLanes']/max(1,c['eventPhases']), c['launchPhases'], c['surfacePhases'], c['walkIterations']/max(1,c['eventPhases'])))
             res = integ.reportResults()
-            print("case=%s bpc=%d priv=%d block=%d thr=%d lthr=%d sthr=%d brick=%d inflight=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
-                a.case, bpc, priv, block, thr, lthr, sthr, brick, inflight, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
+            print("case=%s skip=%d bpc=%d priv=%d block=%d thr=%d lthr=%d sthr=%d brick=%d inflight=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
+                a.case, skip, bpc, priv, block, thr, lthr, sthr, brick, inflight, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
                 res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"]), flush=True)
 
 

@@ -1,0 +1,149 @@
+"""The layer-skipping walk (include/mcbrat.h: mcbrat_set_walk_options) through the C ABI on the GPU.
+
+Inside a horizontal layer whose cells all carry one extinction value the kernel crosses z faces only, takes a run
+of such layers in one step when the photon's optical depth is not used up inside it, and finds the column again
+from the position.  The reference (accumulateExtinctionAlongPath, src/opticalProperties.f95:1697-1814) and the
+oracle stop at every x and y face, which inside such a layer changes nothing but the float rounding of the
+accumulated optical depth.  So: histories against the oracle and against the face-by-face kernel walk
+(layerSkip = 0) on the same Philox streams, the count of faces crossed, and the edge cases of the fold
+(many periodic wraps, reflecting surface under a clear run, irregular spacing)."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+SEED = 4711
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mcbrat3d_amd
+    return mcbrat3d_amd
+
+
+def _integ(M, case, mu0, phi0, skip, rr=True, nsteps=9001):
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=nsteps, useRayTracing=True, useRussianRoulette=rr)
+    # privateTallies = 0: the optical grid stays in global memory, which is where the layer-skipping walk lives
+    # (grids small enough for LDS keep the face-by-face walk)
+    integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=skip)
+    photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+    return dom, integ, photons, new_RandomNumberSequence(SEED)
+
+
+def _same(a, b):
+    return (a["fate"] == b["fate"]) & (a["ix"] == b["ix"]) & (a["iy"] == b["iy"]) & (a["iz"] == b["iz"]) & \
+        (a["nScatter"] == b["nScatter"]) & (np.abs(a["weight"] - b["weight"]) <= 1e-6)
+
+
+def layered(nx=6, ny=5, nz=16, albedo=0.3, seed=11, ssa=0.95):
+    """Every layer has one extinction value (a plane-parallel medium on a multi-column grid, with two vacuum
+    layers in the middle): the whole walk is runs."""
+    rng = np.random.default_rng(seed)
+    prof = rng.uniform(0.5, 12.0, nz)
+    prof[7:9] = 0.0
+    ext = np.broadcast_to(prof, (nx, ny, nz)).copy()
+    return dict(name="layered", xe=0.05 * np.arange(nx + 1), ye=0.07 * np.arange(ny + 1),
+                ze=np.concatenate([[0.0], np.cumsum(rng.uniform(0.02, 0.05, nz))]), albedo=albedo,
+                components=[dict(ext=ext, ssa=np.where(ext > 0, ssa, 0.0), pfIndex=np.ones(ext.shape, np.int32),
+                                 legendre=[cases.hg_legendre(0.8, 32)])])
+
+
+def test_cloud_field_against_face_by_face_walk_and_oracle(M):
+    """Clear air above and below a broken cloud layer (two components): per-photon fates of the layer-skipping
+    walk against the kernel's face-by-face walk and against the oracle; the faces skipped are counted, so the
+    crossings per photon agree; batch fluxes of the same photons agree far inside the Monte Carlo error."""
+    from oracle import oracle as O
+    n = 40000
+    case = cases.landsat_like(n=48, nz=24, n_entries=6)
+    fates, counters, means = {}, {}, {}
+    for skip in (0, 1):
+        dom, integ, photons, rng = _integ(M, case, 0.5, 30.0, skip)
+        fates[skip] = integ.traceFates(dom, rng, photons, n)
+        counters[skip] = integ.counters()
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, rng, photons, n, 2)
+        r = integ.reportResults()
+        means[skip] = np.array([r["meanFluxUp"], r["meanFluxDown"], r["meanFluxAbsorbed"]])
+        integ.finalize()
+    P = cases.oracle_problem(case, nsteps=9001)
+    ref = O.compute_rt(P, O.solar_source(0.5, 30.0), O.philox_rng(SEED, 0), n, want_fates=True)
+    assert _same(fates[1], fates[0]).mean() > 0.99
+    assert _same(fates[1], ref["fates"]).mean() > 0.99
+    for k in ("legs", "crossings", "collisions", "topExits", "surfaceHits"):
+        assert abs(counters[1][k] - counters[0][k]) <= 2e-3 * counters[0][k] + 5, (k, counters[1][k], counters[0][k])
+        assert abs(counters[1][k] - ref["counters"][k]) <= 2e-3 * ref["counters"][k] + 5, (k, counters[1][k], ref["counters"][k])
+    assert np.all(np.abs(means[1] - means[0]) < 1e-3), (means[1], means[0])  # MC error of 4e4 photons: ~2.5e-3
+
+
+@pytest.mark.parametrize("mu0,phi0", [(0.3, 200.0), (1.0, 0.0), (0.02, 45.0)])
+def test_all_layers_uniform(M, mu0, phi0):
+    """A medium made of runs only (two vacuum layers inside), reflecting surface: launch, collision, surface and
+    top exit all happen on the layer-skipping walk.  mu0 = 0.02 sends the direct beam around the periodic domain
+    about forty times before its first collision."""
+    from oracle import oracle as O
+    n = 30000
+    case = layered()
+    dom, integ, photons, rng = _integ(M, case, mu0, phi0, 1)
+    got = integ.traceFates(dom, rng, photons, n)
+    cg = integ.counters()
+    integ.resetMoments()
+    integ.computeRadiativeTransfer(dom, rng, photons, n)
+    res = integ.reportResults()
+    integ.finalize()
+    P = cases.oracle_problem(case, nsteps=9001)
+    ref = O.compute_rt(P, O.solar_source(mu0, phi0), O.philox_rng(SEED, 0), n, want_fates=True)
+    assert _same(got, ref["fates"]).mean() > 0.99
+    for k in ("legs", "crossings", "collisions", "topExits", "surfaceHits"):
+        assert abs(cg[k] - ref["counters"][k]) <= 3e-3 * ref["counters"][k] + 5, (k, cg[k], ref["counters"][k])
+    norm = O.normalize(P, n, ref)
+    mu, md, ma, prof = O.report_means(P, norm)
+    for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
+        assert abs(g - r) < 3e-3, (g, r)
+    assert np.allclose(res["absorbedProfile"], prof, rtol=0.03, atol=0.01 * np.max(prof))
+    # conservation with a reflecting surface: up + absorbed in the medium + absorbed by the surface = 1
+    assert abs(res["meanFluxUp"] + res["meanFluxAbsorbed"] + (1.0 - case["albedo"]) * res["meanFluxDown"] - 1.0) < 3.0 / np.sqrt(n)
+
+
+def test_vacuum_columns_after_many_wraps(M):
+    """No extinction at all: each photon crosses the whole domain in one step and must land in the column the
+    face-by-face walk of the oracle reaches after wrapping around the domain (grazing sun: ~17 times in x)."""
+    from oracle import oracle as O
+    n = 20000
+    case = layered(albedo=0.0)
+    for c in case["components"]:
+        c["ext"][:] = 0.0
+        c["ssa"][:] = 0.0
+    dom, integ, photons, rng = _integ(M, case, 0.03, 10.0, 1)
+    got = integ.traceFates(dom, rng, photons, n)
+    integ.finalize()
+    P = cases.oracle_problem(case, nsteps=9001)
+    rf = O.compute_rt(P, O.solar_source(0.03, 10.0), O.philox_rng(SEED, 0), n, want_fates=True)["fates"]
+    assert np.all(got["fate"] == 1) and np.all(rf["fate"] == 1)  # absorbed by the black surface
+    # a photon that lands within rounding of a column boundary may be booked next door: a handful in 2e4
+    assert _same(got, rf).mean() > 0.999
+
+
+def test_irregular_columns_with_clear_runs(M):
+    """Geometrically stretched x/y/z spacing (cell lookup by bisection of the edge table) with two clear layers
+    under the cloud and a reflecting surface: layer-skipping against the face-by-face kernel walk."""
+    n = 40000
+    case = cases.stretched_grid_cloud()
+    fates, means = {}, {}
+    for skip in (0, 1):
+        dom, integ, photons, rng = _integ(M, case, 0.6, 75.0, skip)
+        fates[skip] = integ.traceFates(dom, rng, photons, n)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, rng, photons, n, 4)
+        r = integ.reportResults()
+        means[skip] = np.array([r["meanFluxUp"], r["meanFluxDown"], r["meanFluxAbsorbed"]])
+        integ.finalize()
+    # (chaotic medium, see test_stretched_grid_tabulated_phase_functions: a rounding difference in one leg can
+    # change the rest of a long history)
+    assert _same(fates[1], fates[0]).mean() > 0.93
+    short = fates[0]["nScatter"] <= 3
+    assert _same(fates[1], fates[0])[short].mean() > 0.995
+    assert np.all(np.abs(means[1] - means[0]) < 2.5e-3), (means[1], means[0])
