@@ -1,0 +1,101 @@
+"""ctypes binding of include/mcbrat.h (the C ABI of the HIP library).
+
+There is no CPU fallback: if libmcbrat_hip.so is missing or no HIP device is
+usable, importing the symbols or creating a context raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MCBRAT_LIB", os.path.join(_HERE, "libmcbrat_hip.so"))  # MCBRAT_LIB: A/B builds
+_lib = None
+
+
+class McbratError(RuntimeError):
+    """A failure status from the integrator (the reference's stateIsFailure(status))."""
+
+
+class Fate(C.Structure):
+    _fields_ = [("fate", C.c_int32), ("ix", C.c_int32), ("iy", C.c_int32), ("iz", C.c_int32),
+                ("nScatter", C.c_int32), ("nEvents", C.c_int32), ("weight", C.c_float)]
+
+
+FATE_DTYPE = np.dtype([("fate", "<i4"), ("ix", "<i4"), ("iy", "<i4"), ("iz", "<i4"),
+                       ("nScatter", "<i4"), ("nEvents", "<i4"), ("weight", "<f4")])
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("legs", "crossings", "collisions", "absorbEvents", "topExits",
+                                         "surfaceHits", "rouletteKills", "rouletteSurvivals", "walkIterations",
+                                         "walkLanes", "eventPhases", "eventLanes", "launchPhases", "surfacePhases")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+# every symbol include/mcbrat.h declares: (restype, argtypes)
+_vp, _i32, _i64, _u64, _f, _d = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
+SYMBOLS = {
+    "mcbrat_abi_version": (C.c_int, []),
+    "mcbrat_create": (_vp, [C.c_int]),
+    "mcbrat_destroy": (None, [_vp]),
+    "mcbrat_last_error": (C.c_char_p, [_vp]),
+    "mcbrat_set_grid": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "mcbrat_set_optics": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _d]),
+    "mcbrat_set_inverse_table": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
+    "mcbrat_specify_parameters": (C.c_int, [_vp, _i32, _i32, _f]),
+    "mcbrat_set_source_solar": (C.c_int, [_vp, _f, _f]),
+    "mcbrat_set_source_emission": (C.c_int, [_vp, _vp, _d]),
+    "mcbrat_compute_radiative_transfer": (C.c_int, [_vp, _u64, _u64, _i64, _i32, _vp]),
+    "mcbrat_report_results": (C.c_int, [_vp] * 9),
+    "mcbrat_moments_length": (_i64, [_vp]),
+    "mcbrat_bind_moments": (C.c_int, [_vp, _vp]),
+    "mcbrat_reset_moments": (C.c_int, [_vp]),
+    "mcbrat_get_moments": (C.c_int, [_vp, _vp]),
+    "mcbrat_enable_counters": (C.c_int, [_vp, _i32]),
+    "mcbrat_get_counters": (C.c_int, [_vp, _vp]),
+    "mcbrat_last_trace_ms": (_f, [_vp]),
+    "mcbrat_specify_intensity": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _f, _i32, _i32, _i32, _f]),
+    "mcbrat_set_forward_table": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "mcbrat_report_intensity": (C.c_int, [_vp, _vp, _vp]),
+    "mcbrat_forward_table_legendre": (C.c_int, [_i32, _vp, _i32, _vp]),
+    "mcbrat_forward_table_tabulated": (C.c_int, [_i32, _vp, _vp, _i32, _vp]),
+    "mcbrat_hybrid_phase_functions": (C.c_int, [_i32, _i32, _vp, _f, _vp]),
+    "mcbrat_get_event_threshold": (C.c_int, [_vp]),
+    "mcbrat_set_async": (C.c_int, [_vp, _i32]),
+    "mcbrat_synchronize": (C.c_int, [_vp]),
+    "mcbrat_stream_wait_done": (C.c_int, [_vp, _vp]),
+    "mcbrat_wait_stream": (C.c_int, [_vp, _vp]),
+    "mcbrat_set_tuning": (C.c_int, [_vp] + [_i32] * 8),
+    "mcbrat_trace_fates": (C.c_int, [_vp, _u64, _u64, _i64, _vp]),
+    "mcbrat_inverse_table_legendre": (C.c_int, [_i32, _vp, _i32, _vp]),
+    "mcbrat_inverse_table_tabulated": (C.c_int, [_i32, _vp, _vp, _i32, _vp]),
+    "mcbrat_emission_weighting": (C.c_int, [_i32] * 4 + [_vp] * 7 + [_d] * 4 + [_vp] * 3),
+}
+
+
+def lib():
+    """The loaded native library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise McbratError("%s is missing: build it with `python -m mcbrat3d_amd.build` "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def check(ctx, rc):
+    if rc != 0:
+        msg = lib().mcbrat_last_error(ctx)
+        raise McbratError(msg.decode() if msg else "mcbrat: failure %d" % rc)

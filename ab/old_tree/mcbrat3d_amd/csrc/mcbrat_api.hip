@@ -55,8 +55,6 @@ struct mcbrat_ctx {
   uint32_t *dBrickTable = nullptr;
   uint32_t *dRec = nullptr;    // packed collision record per cell (nc <= 2), see DevParams::rec
   float *dLayerExt = nullptr;  // [nz] extinction of a horizontally uniform layer, -1 otherwise
-  int *dLayerRun = nullptr;    // [nz] runs of such layers (DevParams::layerRun)
-  double *dLayerRunT = nullptr;  // [nz+1]
   float *dExtB = nullptr, *dCumB = nullptr, *dSsaB = nullptr, *dBgExt = nullptr, *dBgCum = nullptr, *dBgSsa = nullptr;
   uint16_t *dPfiB = nullptr, *dBgPfi = nullptr;
   int nbx = 0, nby = 0, nbz = 0;
@@ -107,7 +105,6 @@ struct mcbrat_ctx {
   unsigned long long tuneTrialPhotons = 1ull << 24;  // MCBRAT_TUNE_PHOTONS
   int regularWalk = 1;         // equally spaced grids: incremental face distances (MCBRAT_REGULAR_WALK=0 turns it off)
   int gridLdsMode = 1;         // stage the optical grid in LDS when it fits (private-tally mode)
-  int layerSkip = 1;           // layers of one extinction value: cross z faces only (MCBRAT_LAYER_SKIP=0 / mcbrat_set_walk_options)
   bool countersOn = false;
   float lastTraceMs = 0.f;
   mcbrat_counters lastCounters{};
@@ -262,20 +259,6 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
     }
   }
   if (upload(c, &c->dLayerExt, layerExt.data(), layerExt.size())) return 1;
-  {
-    // runs of consecutive one-extinction layers (layer-skipping walk): for layer k the face where its run ends
-    // upwards / downwards, and the vertical optical depth of such layers below every face
-    std::vector<int> run(nz, 0);
-    std::vector<double> runT(nz + 1, 0.0);
-    for (int k = 0; k < nz; ++k) runT[k + 1] = runT[k] + (layerExt[k] >= 0.f ? (double)layerExt[k] * (c->ze[k + 1] - c->ze[k]) : 0.0);
-    for (int k = 0; k < nz; ++k) {
-      int up = k + 1, down = k;
-      while (up < nz && layerExt[up] >= 0.f) ++up;
-      while (down > 0 && layerExt[down - 1] >= 0.f) --down;
-      run[k] = (up << 16) | down;
-    }
-    if (upload(c, &c->dLayerRun, run.data(), run.size()) || upload(c, &c->dLayerRunT, runT.data(), runT.size())) return 1;
-  }
   auto isBackground = [&](size_t v, int k) {
     if (e[v] != bgExt[k]) return false;
     for (int q = 0; q < nc; ++q)
@@ -362,16 +345,6 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.xyRegularWalk = (c->xyRegular && c->regularWalk) ? 1 : 0;
   p.zRegularWalk = (c->zRegular && c->regularWalk) ? 1 : 0;
   p.dXf = (float)((p.xMax - p.x0) / c->nx); p.dYf = (float)((p.yMax - p.y0) / c->ny); p.dZf = (float)((p.zMax - p.z0) / c->nz);
-  p.layerSkip = c->layerSkip ? 1 : 0;
-  p.layerRun = c->dLayerRun; p.layerRunT = c->dLayerRunT;
-  p.invLx = 1.0 / p.Lx; p.invLy = 1.0 / p.Ly;
-  p.invCellX = (double)c->nx / p.Lx; p.invCellY = (double)c->ny / p.Ly;
-  {
-    bool u = true;  // equally spaced to a millionth of a cell: the cell of a position is guessed by division
-    for (int i = 0; i <= c->nx && u; ++i) u = std::fabs((c->xe[i] - p.x0) * p.invCellX - i) <= 1e-6;
-    for (int i = 0; i <= c->ny && u; ++i) u = std::fabs((c->ye[i] - p.y0) * p.invCellY - i) <= 1e-6;
-    p.xyNearUniform = u ? 1 : 0;
-  }
   p.edges = c->dEdges;
   if (use_bricks(c)) {
     p.ext = c->dExtB; p.cum = c->dCumB; p.ssa = c->dSsaB; p.pfi = c->dPfiB;
@@ -407,9 +380,6 @@ constexpr size_t kLdsBudget = 64 * 1024;      // default dynamic-LDS limit per w
 constexpr size_t kTableLdsLimit = 48 * 1024;   // tables above this stay in L2
 constexpr size_t kPrivSlabLimit = 32 * 1024;   // private tally slab above this -> global atomics
 
-// LDS of the per-layer tables: extinction (float), run (int), cumulative optical depth (double, nz + 1 padded to even)
-size_t per_layer_lds(int nz) { return 2 * sizeof(float) * (size_t)((nz + 3) & ~3) + sizeof(double) * (size_t)((nz + 2) & ~1); }
-
 struct LaunchPlan {
   bool tblLds, priv, brick, gridLds;
   int block;
@@ -423,7 +393,7 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
   const size_t slab = sizeof(long long) * slabStride + 16;
   L.priv = c->privMode != 0 && slab <= kPrivSlabLimit;
   L.brick = use_bricks(c);
-  const size_t bg = per_layer_lds(c->nz);  // per-layer extinction (background / one-extinction layers) and the runs of such layers
+  const size_t bg = sizeof(float) * (size_t)((c->nz + 3) & ~3);  // per-layer extinction (background / uniform layers)
   L.tblLds = tbl <= kTableLdsLimit && edges + bg + tbl + (L.priv ? slab : 0) <= kLdsBudget;
   if (L.priv && edges + bg + slab + (L.tblLds ? tbl : 0) > kLdsBudget) L.priv = false;
   // small domains: the optical grid itself (ext + per-component cum, ssa, phase index) goes to LDS when it fits
@@ -436,7 +406,7 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
 }
 
 size_t plan_launch_lds(const mcbrat_ctx *c, const LaunchPlan &L) {
-  return sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3) + per_layer_lds(c->nz) +
+  return sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3) + sizeof(float) * (size_t)((c->nz + 3) & ~3) +
          (L.tblLds ? sizeof(float) * (size_t)c->tblTotalFloats : 0);
 }
 
@@ -559,7 +529,6 @@ mcbrat_ctx *mcbrat_create(int device) {
   mcbrat_ctx *c = new mcbrat_ctx();
   c->device = device;
   if (const char *e = getenv("MCBRAT_REGULAR_WALK")) c->regularWalk = atoi(e);
-  if (const char *e = getenv("MCBRAT_LAYER_SKIP")) c->layerSkip = atoi(e);
   if (const char *e = getenv("MCBRAT_TUNE_PHOTONS")) c->tuneTrialPhotons = strtoull(e, nullptr, 10);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCUs = prop.multiProcessorCount;
@@ -577,7 +546,7 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   (void)sync_all(c);
   void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF,
                   c->dEventCounters, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
-                  c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT};
+                  c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (mcbrat_ctx::Lane &L : c->lane) {
     void *lb[] = {L.dCounter, L.dSlabs, L.dColVals, L.dScalVals};
@@ -945,12 +914,6 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   if (launchThreshold > 0) c->launchThreshold = launchThreshold;
   if (surfaceThreshold > 0) c->surfaceThreshold = surfaceThreshold;
   if (brickLayout >= 0 && brickLayout <= 2) { if (brickLayout != c->brickMode) c->tuned = false; c->brickMode = brickLayout; }
-  return 0;
-}
-
-int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip) {
-  if (!c) return 1;
-  if (layerSkip >= 0) { if ((layerSkip != 0) != (c->layerSkip != 0)) c->tuned = false; c->layerSkip = layerSkip ? 1 : 0; }
   return 0;
 }
 

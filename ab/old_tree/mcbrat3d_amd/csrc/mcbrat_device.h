@@ -12,10 +12,7 @@ constexpr double kTallyScale = 4294967296.0;  // tallies are signed 64-bit fixed
 constexpr double kTallyInv = 1.0 / 4294967296.0;
 
 // States of a lane in the tracing loop.
-// ST_ENTER: a lane on the layer-skipping walk has reached a layer whose extinction varies from cell to cell and
-// waits for the event phase to bring its x/y state up to date.
-// ST_JUMP: a lane has entered a run of such layers and waits for the event phase to take the run in one step.
-enum : int { ST_DEAD = 0, ST_WALK = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_TOP = 4, ST_ENTER = 5, ST_JUMP = 6 };
+enum : int { ST_DEAD = 0, ST_WALK = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_TOP = 4 };
 
 struct DevParams {
   // grid (set_grid)
@@ -26,14 +23,6 @@ struct DevParams {
   double invDX, invDY;            // 1/deltaX, 1/deltaY when xyRegular
   int xyRegularWalk, zRegularWalk; // equally spaced axes: the walk steps their face distances by dXf|1/dir| etc.
   float dXf, dYf, dZf;
-  // layer-skipping walk (dense layout): in a layer with one extinction value only z faces are crossed; the x/y
-  // cell is found again from the position (periodic fold + cell lookup) when the lane leaves such layers
-  int layerSkip;
-  const int *layerRun;            // [nz] run of one-extinction layers around layer k: face where it ends upwards << 16 | downwards
-  const double *layerRunT;        // [nz+1] vertical optical depth of the one-extinction layers below face f
-  int xyNearUniform;              // x and y edges equally spaced to 1e-6 of a cell: cell guess by division, table decides
-  double invLx, invLy;            // 1 / domain length
-  double invCellX, invCellY;      // nx / Lx, ny / Ly
   const double *edges;            // [xe(nx+1) | ye(ny+1) | ze(nz+1)]
   // optics (set_optics), float copies of the reference's real(8) arrays
   const float *ext;               // [nvox]

@@ -1,0 +1,65 @@
+"""Development timing loop (not the judged bench): step cloud / landsat-like, sweeps of tuning knobs."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from tests import cases  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="step")
+    ap.add_argument("--ppb", type=int, default=100000)
+    ap.add_argument("--batches", type=int, default=100)
+    ap.add_argument("--thr", type=int, nargs="*", default=[40])
+    ap.add_argument("--bpc", type=int, nargs="*", default=[0])
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--ssa", type=float, default=0.99)
+    ap.add_argument("--counters", action="store_true")
+    ap.add_argument("--inflight", type=int, nargs="*", default=[-1])
+    ap.add_argument("--lthr", type=int, nargs="*", default=[0])
+    ap.add_argument("--sthr", type=int, nargs="*", default=[0])
+    ap.add_argument("--priv", type=int, nargs="*", default=[-1])
+    ap.add_argument("--brick", type=int, nargs="*", default=[-1])
+    ap.add_argument("--block", type=int, nargs="*", default=[-1])
+    a = ap.parse_args()
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.step_cloud(a.ssa) if a.case == "step" else (cases.radar_like() if a.case == "radar" else cases.landsat_like(ssa_cloud=a.ssa))
+    mu0, phi0 = (1.0, 0.0) if a.case == "step" else (0.5, 30.0)
+    t0 = time.time()
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=10001)
+    photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
+    print("setup %.2fs" % (time.time() - t0), flush=True)
+    import itertools
+    for bpc, priv, block, thr, lthr, sthr, brick in itertools.product(a.bpc, a.priv, a.block, a.thr, a.lthr, a.sthr, a.brick):
+      for inflight in a.inflight:
+        if True:
+            integ.setTuning(blocksPerCU=bpc, eventThreshold=thr, privateTallies=priv, blockSize=block, launchThreshold=lthr, surfaceThreshold=sthr, brickLayout=brick, maxBatchesInFlight=inflight)
+            rates = []
+            for r in range(a.reps):
+                rng = new_RandomNumberSequence(1234 + r)
+                integ.resetMoments()
+                t = time.time()
+                n = integ.computeRadiativeTransfer(dom, rng, photons, a.ppb, a.batches)
+                dt = time.time() - t
+                rates.append((n / dt, n / (integ.lastTraceMs() * 1e-3)))
+            if a.counters:
+                integ.enableCounters(True)
+                integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(99), photons, a.ppb, a.batches)
+                c = integ.counters(); integ.enableCounters(False)
+                print('   walk iters %.4g lanes/iter %.1f | event phases %.4g lanes/phase %.1f | launch phases %.4g surf phases %.4g | walk iters per event phase %.2f' % (c['walkIterations'], c['walkLanes']/max(1,c['walkIterations']), c['eventPhases'], c['eventLanes']/max(1,c['eventPhases']), c['launchPhases'], c['surfacePhases'], c['walkIterations']/max(1,c['eventPhases'])))
+            res = integ.reportResults()
+            print("case=%s bpc=%d priv=%d block=%d thr=%d lthr=%d sthr=%d brick=%d inflight=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
+                a.case, bpc, priv, block, thr, lthr, sthr, brick, inflight, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
+                res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

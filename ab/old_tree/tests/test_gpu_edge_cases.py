@@ -1,0 +1,200 @@
+"""Edge cases of the domain, through the C ABI on the GPU: tiny and ragged photon counts, more
+batches than workgroups, reflecting surface, vacuum, grazing sun, roulette off, private vs
+global tallies, and size-independent properties at BASELINE.json's full photon counts."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+SEED = 31337
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mcbrat3d_amd
+    return mcbrat3d_amd
+
+
+def _run(M, case, mu0, phi0, ppb, nb, rr=True, seed=SEED, tuning=None, first=0):
+    from mcbrat3d_amd import driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=rr)
+    if tuning:
+        integ.setTuning(**tuning)
+    photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
+    integ.resetMoments()
+    n = integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(seed, first), photons, ppb, nb)
+    mom = integ.moments()
+    st = driver.statistics(driver.unpack_moments(mom, dom.numX, dom.numY, dom.numZ))
+    last = integ.reportResults()
+    integ.finalize()
+    return n, st, last, mom
+
+
+def _oracle(case, mu0, phi0, n, rr=True, seed=SEED, first=0):
+    from oracle import oracle as O
+    P = cases.oracle_problem(case, nsteps=9001, use_russian_roulette=rr)
+    return O.compute_radiative_transfer(P, O.solar_source(mu0, phi0), O.philox_rng(seed, first), n)
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 257, 1000])
+def test_tiny_and_ragged_photon_counts(M, n):
+    """Fewer photons than lanes in a wave / not a multiple of anything."""
+    case = cases.step_cloud(0.99)
+    done, st, last, _ = _run(M, case, 1.0, 0.0, n, 1)
+    ref = _oracle(case, 1.0, 0.0, n)
+    assert done == n and st["totalPhotons"] == n
+    assert np.allclose(last["fluxUp"][:, 0], ref["fluxUp"], atol=32.0 / n * 1.01 * (n > 200) + 1e-5)
+    assert abs(last["meanFluxUp"] + last["meanFluxDown"] + last["meanFluxAbsorbed"] - 1.0) < 0.05 + 2.0 / n
+
+
+def test_more_batches_than_workgroups(M):
+    """3000 batches of 512 photons: workgroups loop over units; moments fold every batch."""
+    case = cases.plane_parallel(ssa=0.9)
+    done, st, _, _ = _run(M, case, 1.0, 0.0, 512, 3000)
+    assert done == 512 * 3000 and st["batches"] == 3000
+    ref = _oracle(case, 1.0, 0.0, 200000)
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert abs(st[k] - ref[k]) < 5 * np.sqrt(st[k + "_StdErr"] ** 2 + 0.25 / 200000) + 1e-4, k
+    assert 0 < st["meanFluxUp_StdErr"] < 2e-3
+
+
+def test_private_and_global_tallies_agree_bitwise(M):
+    """LDS-private slabs (small domains) and global atomics are both exact integer sums."""
+    case = cases.step_cloud(0.99)
+    _, _, _, a = _run(M, case, 0.5, 30.0, 20000, 7, tuning=dict(privateTallies=1))
+    _, _, _, b = _run(M, case, 0.5, 30.0, 20000, 7, tuning=dict(privateTallies=0, blockSize=256, eventThreshold=40))
+    assert np.array_equal(a, b)
+
+
+def test_reflecting_surface_and_no_roulette(M):
+    """Lambertian albedo 0.6: photons bounce off the surface repeatedly (computeRT :619-676)."""
+    case = cases.step_cloud(1.0)
+    case["albedo"] = 0.6
+    n = 60000
+    done, st, last, _ = _run(M, case, 0.5, 0.0, n, 1, rr=False)
+    ref = _oracle(case, 0.5, 0.0, n, rr=False)
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert abs(last[k] - ref[k]) < 30.0 / n, (k, last[k], ref[k])
+    assert last["meanFluxDown"] > 0.5 and last["meanFluxAbsorbed"] == 0.0
+    # conservative medium: what comes down and is not reflected is absorbed by the surface
+    assert abs(last["meanFluxUp"] + (1 - 0.6) * last["meanFluxDown"] - 1.0) < 2e-3
+
+
+def test_vacuum_and_grazing_sun(M):
+    """Zero extinction everywhere: every photon reaches the surface in its launch column,
+    after wrapping around the periodic domain many times for a grazing sun."""
+    case = cases.step_cloud(1.0)
+    case["components"][0]["ext"][:] = 0.0
+    for mu0 in (1.0, 0.02):
+        n = 20000
+        done, st, last, _ = _run(M, case, mu0, 45.0, n, 1)
+        assert done == n
+        assert last["meanFluxDown"] == pytest.approx(1.0, abs=1e-6)
+        assert last["meanFluxUp"] == 0.0 and last["meanFluxAbsorbed"] == 0.0
+        assert np.all(last["volumeAbsorption"] == 0.0)
+
+
+def test_full_size_properties_step_cloud(M):
+    """BASELINE.json configs[1] at full size (1e7 photons) and the accuracy target's size (1e8):
+    properties that need no reference run -- energy closure, mean of the batch means equals the
+    whole, column sums equal domain means, independence of how the batches are cut."""
+    case = cases.step_cloud(0.99)
+    n1, st1, _, m1 = _run(M, case, 1.0, 0.0, 100000, 100)
+    n2, st2, _, m2 = _run(M, case, 1.0, 0.0, 1000000, 10)
+    assert n1 == n2 == 10 ** 7
+    closure = st1["meanFluxUp"] + st1["meanFluxDown"] + st1["meanFluxAbsorbed"]
+    assert abs(closure - 1.0) < 3.0 / np.sqrt(n1)  # roulette leaves closure only statistically exact
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert abs(st1[k] - st2[k]) < 1e-6  # same photons, different batching: float32 normalisation only
+        assert abs(st1[k.replace("meanF", "f")].mean() - st1[k]) < 1e-6
+    assert abs(st1["absorbedProfile"].sum() * 0.0078125 * 1000.0 - st1["meanFluxAbsorbed"]) < 1e-5
+    n3, st3, _, _ = _run(M, case, 1.0, 0.0, 1000000, 100, seed=2)
+    assert n3 == 10 ** 8
+    assert abs(st3["meanFluxUp"] + st3["meanFluxDown"] + st3["meanFluxAbsorbed"] - 1.0) < 3.0 / np.sqrt(n3)
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert abs(st3[k] - st1[k]) < 5 * np.sqrt(st3[k + "_StdErr"] ** 2 + st1[k + "_StdErr"] ** 2)
+
+
+def test_error_paths_through_the_abi(M):
+    case = cases.step_cloud(0.99)
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    with pytest.raises(M.McbratError, match="useRayTracing"):
+        integ.specifyParameters(useRayTracing=False)
+    integ.useRayTracing = True
+    with pytest.raises(M.McbratError, match="intensity"):
+        integ.specifyParameters(computeIntensity=True)
+    with pytest.raises(M.McbratError, match="no batch"):
+        integ.reportResults()
+    photons = M.new_PhotonStream(1.0, 0.0, numberOfPhotons=0)
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    with pytest.raises(M.McbratError, match="Didn't process any photons"):
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(1), photons, 1000)
+    integ.finalize()
+
+
+def test_brick_layout_is_lossless(M):
+    """4x4x4 bricks with unstored background bricks vs the dense grids: the kernel must read the
+    same floats, so the moment arrays are bitwise equal -- on a cloud field with a large clear
+    fraction (two components) and on a domain without any background (all bricks stored, with
+    ragged brick edges: 30 x 3 x 13 cells)."""
+    case = cases.landsat_like(n=48, nz=24, n_entries=6)
+    _, _, _, a = _run(M, case, 0.5, 30.0, 30000, 4, tuning=dict(brickLayout=0, eventThreshold=32))
+    _, _, _, b = _run(M, case, 0.5, 30.0, 30000, 4, tuning=dict(brickLayout=1, eventThreshold=32))
+    assert np.array_equal(a, b)
+    rng = np.random.default_rng(5)
+    ext = rng.uniform(0.5, 40.0, (30, 3, 13))
+    odd = dict(name="odd", xe=0.01 * np.arange(31), ye=0.02 * np.arange(4), ze=np.concatenate([[0.0], np.cumsum(rng.uniform(0.01, 0.03, 13))]),
+               components=[dict(ext=ext, ssa=rng.uniform(0.8, 1.0, ext.shape), pfIndex=rng.integers(1, 4, ext.shape).astype(np.int32),
+                                legendre=[cases.hg_legendre(g, 16) for g in (0.6, 0.75, 0.85)])], albedo=0.3)
+    _, _, _, a = _run(M, odd, 0.7, 120.0, 20000, 3, tuning=dict(brickLayout=0, privateTallies=0))
+    _, _, _, b = _run(M, odd, 0.7, 120.0, 20000, 3, tuning=dict(brickLayout=1, privateTallies=0))
+    assert np.array_equal(a, b)
+    ref = _oracle(odd, 0.7, 120.0, 20000)
+    _, _, last, _ = _run(M, odd, 0.7, 120.0, 20000, 1, tuning=dict(brickLayout=1))
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert abs(last[k] - ref[k]) < 2e-3, (k, last[k], ref[k])
+
+
+def test_async_calls_overlap_and_match_synchronous_mode(M):
+    """The reference's driver calls computeRadiativeTransfer once per batch (monteCarloDriver.f95:1008).
+    In asynchronous mode those calls overlap on the GPU; moments are folded in call order, so they must
+    be bitwise what the synchronous calls give -- also with a reset in between and a ragged last call."""
+    import time
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.step_cloud(0.99)
+    dom = cases.product_domain(case)
+    photons = M.new_PhotonStream(1.0, 0.0, numberOfPhotons=10 ** 12)
+    out = {}
+    for mode in ("sync", "async", "async_auto"):
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001)
+        if mode != "async_auto":  # (default: the library picks the threshold; calls this small get its guess, 16 here)
+            integ.setTuning(eventThreshold=16)
+        integ.setAsync(mode != "sync")
+        rng = new_RandomNumberSequence(SEED)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, rng, photons, 20000, 3)   # discarded by the reset below
+        integ.resetMoments()
+        integ.synchronize()
+        t0 = time.time()
+        for k in range(40):
+            integ.computeRadiativeTransfer(dom, rng, photons, 50000 if k < 39 else 12345, 1)
+        integ.synchronize()
+        dt = time.time() - t0
+        out[mode] = (integ.moments(), integ.reportResults(), dt, integ.lastTraceMs())
+        integ.finalize()
+    ms, rs, ts, ks = out["sync"]
+    ma, ra, ta, ka = out["async"]
+    assert np.array_equal(ms, out["async_auto"][0]) and out["async_auto"][2] < 1.5 * ts
+    assert ms[0] == ma[0] == 39 * 50000 + 12345 and ms[1] == ma[1] == 40
+    assert np.array_equal(ms, ma)
+    for k in rs:
+        assert np.array_equal(np.asarray(rs[k]), np.asarray(ra[k])), k
+    assert ka > 0.0
+    print("40 per-batch calls: synchronous %.1f ms, asynchronous %.1f ms (kernel time %.1f / %.1f ms)" % (ts * 1e3, ta * 1e3, ks, ka))
+    assert ta < 1.5 * ts  # normally about half (the drain of one call overlaps the next); loose: wall clocks on a shared box

@@ -1,0 +1,205 @@
+"""Radiance by local estimation on the GPU (computeIntensityContribution,
+Integrators/monteCarloRadiativeTransfer.f95:1623-1832) against the ORACLE run on the same Philox
+streams, through the C ABI.  Same random numbers -> the same photon histories (up to the last-bit
+flips described in DESIGN.md), so the per-pixel radiances of one batch agree far inside the Monte
+Carlo noise; known answers and error paths besides."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+SEED = 424242
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mcbrat3d_amd
+    return mcbrat3d_amd
+
+
+def _gpu(M, case, mu0, phi0, n, mus, phis, nb=1, lw=False, seed=SEED, n_angles=9001, **kw):
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    if lw:
+        w = M.new_Weights(dom.numX, dom.numY, dom.numZ)
+        M.emission_weighting(dom, w, case["sfc_temp"])
+        photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 12)
+    else:
+        photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
+    integ.specifyParameters(minInverseTableSize=9001, minForwardTableSize=n_angles, LW_flag=1.0 if lw else -1.0,
+                            intensityMus=mus, intensityPhis=phis, computeIntensity=True, **kw)
+    integ.resetMoments()
+    done = integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(seed), photons, n, nb)
+    assert done == n * nb
+    res = integ.reportResults()
+    mom = integ.moments()
+    integ.finalize()
+    return res, mom, dom
+
+
+def _oracle(case, mu0, phi0, n, mus, phis, lw=False, seed=SEED, first=0, n_angles=9001, hybrid_width=None, **kw):
+    from oracle import oracle as O
+    P = cases.oracle_problem(case, nsteps=9001, lw_flag=1.0 if lw else -1.0)
+    I = cases.oracle_intensity(case, mus, phis, n_angles=n_angles, hybrid_width=hybrid_width, **kw)
+    if lw:
+        vw, frac, _ = O.emission_weighting(P, case["temps"].transpose(2, 1, 0).reshape(-1), case["lambda_um"], case["sfc_temp"])
+        src = O.EmissionSource(vw, frac)
+    else:
+        src = O.solar_source(mu0, phi0)
+    return O.compute_radiative_transfer_intensity(P, src, O.philox_rng(seed, first), n, I)
+
+
+def _as_xyd(ref, nx, ny):
+    return ref["intensity"].reshape(-1, ny, nx).transpose(2, 1, 0)
+
+
+def test_lambertian_surface_under_vacuum_is_exact(M):
+    case = cases.plane_parallel(ssa=1.0)
+    case["components"][0]["ext"] = np.zeros_like(case["components"][0]["ext"])
+    case["albedo"] = 0.3
+    for rr in (False, True):
+        res, _, _ = _gpu(M, case, 0.7, 30.0, 5000, [1.0, 0.5, 0.2], [0.0, 90.0, 200.0], n_angles=9001,
+                         useRussianRouletteForIntensity=rr)
+        assert np.allclose(res["meanIntensity"], 0.3 / np.pi, rtol=1e-6), (rr, res["meanIntensity"])
+        assert res["intensity"].shape == (1, 1, 3)
+
+
+@pytest.mark.parametrize("rr", [False, True])
+def test_step_cloud_radiance_matches_oracle_per_pixel(M, rr):
+    """I3RC step cloud, three upward directions.  One batch of 40000 photons on identical streams."""
+    case = cases.step_cloud(0.99)
+    mus, phis = [1.0, 0.5, 0.25], [0.0, 180.0, 0.0]
+    n = 40000
+    res, _, dom = _gpu(M, case, 1.0, 0.0, n, mus, phis, useRussianRouletteForIntensity=rr, zetaMin=0.3)
+    ref = _oracle(case, 1.0, 0.0, n, mus, phis, use_russian_roulette=rr, zeta_min=0.3)
+    g, r = res["intensity"], _as_xyd(ref, 32, 1)
+    assert g.shape == r.shape == (32, 1, 3)
+    # identical histories except ~1e-5 of them: pixel values agree to a few 1e-3 of the mean radiance
+    scale = float(np.mean(r))
+    assert np.max(np.abs(g - r)) < (0.03 if rr else 0.01) * scale + 1e-6, np.max(np.abs(g - r)) / scale
+    assert np.allclose(res["meanIntensity"], ref["meanIntensity"], rtol=2e-3 if rr else 5e-4)
+    assert abs(res["meanFluxUp"] - ref["meanFluxUp"]) < 2e-4
+
+
+def test_downward_view_and_plane_parallel(M):
+    """Radiance leaving through the surface (mu < 0, without roulette) and through the top."""
+    case = cases.plane_parallel(ssa=0.95)
+    case["albedo"] = 0.2
+    mus, phis = [-0.8, 0.8, -0.3], [0.0, 45.0, 270.0]
+    n = 30000
+    res, _, _ = _gpu(M, case, 0.6, 10.0, n, mus, phis)
+    ref = _oracle(case, 0.6, 10.0, n, mus, phis)
+    assert np.allclose(res["meanIntensity"], ref["meanIntensity"], rtol=1e-3), (res["meanIntensity"], ref["meanIntensity"])
+    assert np.all(res["meanIntensity"] > 0)
+
+
+def test_two_components_and_hybrid_phase_functions(M):
+    """128x128x64-like scene reduced to 24x24x16: two components, multi-entry tables; hybrid tables beyond
+    the second order of scattering."""
+    case = cases.landsat_like(n=24, nz=16)
+    for comp in case["components"]:  # a sharper forward peak so that a transition angle exists
+        if len(comp["legendre"]) > 1:
+            comp["legendre"] = [cases.hg_legendre(0.93, 200) for _ in comp["legendre"]]
+    mus, phis = [1.0, 0.6], [0.0, 120.0]
+    n = 50000
+    kw = dict(useHybridPhaseFunsForIntenCalcs=True, hybridPhaseFunWidth=7.0, numOrdersOrigPhaseFunIntenCalcs=2)
+    res, _, _ = _gpu(M, case, 0.5, 30.0, n, mus, phis, n_angles=9001, **kw)
+    ref = _oracle(case, 0.5, 30.0, n, mus, phis, n_angles=9001, hybrid_width=7.0, num_orders_orig=2)
+    assert np.allclose(res["meanIntensity"], ref["meanIntensity"], rtol=4e-3), (res["meanIntensity"], ref["meanIntensity"])
+    g, r = res["intensity"], _as_xyd(ref, 24, 24)
+    # smooth fields: compare 4x4 block means (each ~1400 photons' worth of contributions)
+    gb = g.reshape(6, 4, 6, 4, 2).mean(axis=(1, 3))
+    rb = r.reshape(6, 4, 6, 4, 2).mean(axis=(1, 3))
+    assert np.max(np.abs(gb - rb)) < 0.05 * float(np.mean(rb)), np.max(np.abs(gb - rb)) / float(np.mean(rb))
+
+
+def test_thermal_emission_radiance(M):
+    """LW: emission seen directly (isotropic source in the atmosphere, Lambertian surface emission) plus the
+    scattered part (:510-541)."""
+    case = cases.homog_lw(n=12)
+    mus, phis = [1.0, 0.5], [0.0, 0.0]
+    n = 40000
+    res, _, _ = _gpu(M, case, 1.0, 0.0, n, mus, phis, lw=True)
+    ref = _oracle(case, 1.0, 0.0, n, mus, phis, lw=True)
+    assert np.allclose(res["meanIntensity"], ref["meanIntensity"], rtol=2e-3), (res["meanIntensity"], ref["meanIntensity"])
+    assert np.all(res["meanIntensity"] > 0)
+
+
+def test_limited_contributions_redistribute_the_excess(M):
+    """limitIntensityContributions (:1815-1826, :294-320): local estimates are clipped at maxIntensityContribution
+    and the clipped excess of each (component, direction) is spread in proportion to that component's radiance
+    field.  A strongly peaked phase function and a low cap so that a good part of the radiance is excess."""
+    case = cases.step_cloud(0.99, g=0.93, nleg=200)
+    mus, phis = [1.0, 0.6], [0.0, 180.0]
+    n = 40000
+    kw = dict(limitIntensityContributions=True, maxIntensityContribution=0.02)
+    res, _, _ = _gpu(M, case, 1.0, 0.0, n, mus, phis, **kw)
+    ref = _oracle(case, 1.0, 0.0, n, mus, phis, limit_contributions=True, max_contribution=0.02)
+    plain = _oracle(case, 1.0, 0.0, n, mus, phis)
+    g, r = res["intensity"], _as_xyd(ref, 32, 1)
+    assert float(np.sum(ref["intensityExcess"] if "intensityExcess" in ref else 0)) >= 0
+    assert np.max(np.abs(g - r)) < 0.01 * float(np.mean(r)), np.max(np.abs(g - r)) / float(np.mean(r))
+    # the total radiance is conserved by the redistribution (means equal the unclipped run), the field is smoother
+    assert np.allclose(res["meanIntensity"], plain["meanIntensity"], rtol=2e-3)
+    assert np.std(g[:, 0, 0]) < np.std(_as_xyd(plain, 32, 1)[:, 0, 0])
+
+
+def test_radiance_moments_statistics_and_reproducibility(M):
+    """Batch moments carry the radiance (RadianceStats, monteCarloDriver.f95:1047-1050); mean over batches
+    agrees with a long oracle run inside the combined standard error; reruns are bitwise identical; a run
+    split over two calls gives the same moments."""
+    from mcbrat3d_amd import driver
+    case = cases.step_cloud(0.99)
+    mus, phis = [1.0, 0.4], [0.0, 180.0]
+    res, mom, dom = _gpu(M, case, 1.0, 0.0, 20000, mus, phis, nb=8, useRussianRouletteForIntensity=True)
+    res2, mom2, _ = _gpu(M, case, 1.0, 0.0, 20000, mus, phis, nb=8, useRussianRouletteForIntensity=True)
+    assert np.array_equal(mom, mom2)
+    st = driver.statistics(driver.unpack_moments(mom, 32, 1, 32))
+    assert st["intensity"].shape == (32, 1, 2) and st["batches"] == 8
+    from oracle import oracle as O
+    P = cases.oracle_problem(case, nsteps=9001)
+    I = cases.oracle_intensity(case, mus, phis, use_russian_roulette=True)
+    batches = []
+    rng = O.mt_rng(77)
+    for b in range(8):
+        batches.append(O.compute_radiative_transfer_intensity(P, O.solar_source(1.0, 0.0), rng, 20000, I)["intensity"])
+    ref = np.array(batches)  # [batch, dir, col]
+    rmean, rerr = ref.mean(0), ref.std(0, ddof=1) / np.sqrt(8)
+    gmean = st["intensity"][:, 0, :].T
+    gerr = st["intensity_StdErr"][:, 0, :].T
+    z = (gmean - rmean) / np.sqrt(gerr ** 2 + rerr ** 2 + 1e-30)
+    assert np.max(np.abs(z)) < 5.0 and abs(np.mean(z)) < 0.6, (np.max(np.abs(z)), np.mean(z))
+
+
+def test_intensity_error_paths(M):
+    from mcbrat3d_amd._capi import McbratError
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.plane_parallel(ssa=0.9)
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    with pytest.raises(McbratError, match="upward"):
+        integ.specifyParameters(intensityMus=[-0.5], intensityPhis=[0.0], useRussianRouletteForIntensity=True)
+    integ.specifyParameters(useRussianRouletteForIntensity=False)
+    with pytest.raises(McbratError, match="sideways"):
+        integ.specifyParameters(intensityMus=[0.0], intensityPhis=[0.0])
+    with pytest.raises(McbratError, match="between 0 and 360"):
+        integ.specifyParameters(intensityMus=[0.5], intensityPhis=[400.0])
+    integ.specifyParameters(intensityMus=[0.5], intensityPhis=[0.0], limitIntensityContributions=False)
+    photons = M.new_PhotonStream(1.0, 0.0, numberOfPhotons=10 ** 9)
+    integ.enableCounters(True)
+    with pytest.raises(McbratError, match="counters"):
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(1), photons, 1000)
+    integ.enableCounters(False)
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(1), photons, 1000) == 1000
+    assert integ.reportResults()["intensity"].shape == (1, 1, 1)
+    # turning intensity off again restores the flux-only moment layout
+    n1 = integ.momentsLength()
+    integ.specifyParameters(computeIntensity=False)
+    assert integ.momentsLength() == n1 - 1
+    with pytest.raises(McbratError, match="no batch"):  # results of the old layout are dropped with it
+        integ.reportResults()
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(1), photons, 1000) == 1000
+    assert "intensity" not in integ.reportResults()
+    integ.finalize()
