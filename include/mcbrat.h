@@ -184,13 +184,17 @@ int mcbrat_set_tuning(mcbrat_ctx *ctx, int32_t blocksPerCU, int32_t eventThresho
                       int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold,
                       int32_t brickLayout);
 
-/* Walk options (negative = leave unchanged).  layerSkip (default 1): inside a horizontal layer whose cells all
- * carry one extinction value -- the clear air above and below a cloud field -- a photon crosses z faces only;
- * its column is found again from its position when it collides, leaves the domain or reaches a layer with
- * cell-to-cell extinction.  The reference's accumulateExtinctionAlongPath (src/opticalProperties.f95:1697-1814)
- * stops at every x and y face too, which changes nothing inside such a layer but the float rounding of the
- * accumulated optical depth; 0 restores that face-by-face walk (used by the per-photon identity tests). */
-int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip);
+/* Walk options (negative = leave unchanged).
+ * layerSkip (default 1): inside a horizontal layer whose cells all carry one extinction value -- the clear air
+ * above and below a cloud field -- a photon crosses z faces only; its column is found again from its position when
+ * it collides, leaves the domain or reaches a layer with cell-to-cell extinction.  The reference's
+ * accumulateExtinctionAlongPath (src/opticalProperties.f95:1697-1814) stops at every x and y face too, which changes
+ * nothing inside such a layer but the float rounding of the accumulated optical depth; 0 restores that face-by-face
+ * walk (used by the per-photon identity tests).
+ * exchange (default 1): flux runs with the directional source use the photon-exchange form of the tracing kernel
+ * (photons move between waves at leg boundaries through LDS queues, so that walking and event processing both run
+ * with nearly all lanes busy); results are bitwise those of the one-photon-per-lane kernel, which 0 selects. */
+int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t exchange);
 
 /* The event threshold in use (after the first call of a domain: the one chosen by the trial launches). */
 int mcbrat_get_event_threshold(const mcbrat_ctx *ctx);

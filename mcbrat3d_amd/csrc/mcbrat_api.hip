@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "mcbrat_kernels.hip"
+#include "mcbrat_exchange.hip"
 
 using namespace mcbrat;
 
@@ -41,6 +42,7 @@ struct mcbrat_ctx {
   Lane &L() { return lane[cur]; }
   std::string err;
   int numCUs = 256;
+  size_t ldsPerCU = 160 * 1024;
   // grid
   int nx = 0, ny = 0, nz = 0, nc = 0;
   bool haveGrid = false, haveOptics = false, haveSource = false;
@@ -107,6 +109,8 @@ struct mcbrat_ctx {
   unsigned long long tuneTrialPhotons = 1ull << 24;  // MCBRAT_TUNE_PHOTONS
   int regularWalk = 1;         // equally spaced grids: incremental face distances (MCBRAT_REGULAR_WALK=0 turns it off)
   int gridLdsMode = 1;         // stage the optical grid in LDS when it fits (private-tally mode)
+  int exchangeMode = 1;        // photon-exchange form of the tracing kernel where it applies (MCBRAT_EXCHANGE=0 / mcbrat_set_walk_options)
+  int flushLanes = 16;         // exchange kernel: lanes of a wave that have stopped before it hands legs over (MCBRAT_FLUSH_LANES)
   int layerSkip = 1;           // layers of one extinction value: cross z faces only (MCBRAT_LAYER_SKIP=0 / mcbrat_set_walk_options)
   bool countersOn = false;
   float lastTraceMs = 0.f;
@@ -488,12 +492,51 @@ int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatche
                   : launch_trace_t<BLOCK, false, 0, false, DBG>(c, p, L.lds, nBatches);
 }
 
+// Photon-exchange form of the tracing kernel (mcbrat_exchange.hip): workgroups of 512 lanes, 11/8 photon slots per lane.
+constexpr int kXBlock = 512, kXSlots = 704;
+size_t exchange_lds(const LaunchPlan &L) { return ((L.lds + 15) & ~(size_t)15) + 32 + 3 * kXCells * sizeof(unsigned) + (size_t)kXSlots * 80; }
+
+bool exchange_applies(const mcbrat_ctx *c, const LaunchPlan &L, bool debug) {
+  return c->exchangeMode != 0 && !debug && c->nDir == 0 && !L.brick && c->srcKind == 0 && !(c->lwFlag > 0.f) &&
+         c->nx <= 1024 && c->ny <= 1024 && c->nz <= 1024 && exchange_lds(L) <= (size_t)c->ldsPerCU;
+}
+
+template <bool TBL, int PRIV>
+int launch_trace_x(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatches) {
+  const size_t lds = exchange_lds(L);
+  auto kernel = trace_kernel_x<kXBlock, TBL, PRIV>;
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int perCU = c->blocksPerCU;
+  if (perCU <= 0) {
+    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kXBlock, lds));
+    perCU = std::max(1, std::min(perCU, 8));
+  }
+  unsigned long long blocks = (unsigned long long)perCU * c->numCUs;
+  if (PRIV) {
+    unsigned long long upb = std::max<unsigned long long>(1, blocks / (unsigned long long)nBatches);
+    upb = std::min<unsigned long long>(upb, std::max<unsigned long long>(1, p.ppb / (unsigned long long)(kXBlock * 8)));
+    p.unitsPerBatch = upb;
+    p.nUnits = upb * (unsigned long long)nBatches;
+    blocks = std::min(blocks, p.nUnits);
+  } else {
+    blocks = std::min(blocks, (p.total + kXBlock - 1) / kXBlock);
+  }
+  hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<unsigned long long>(1, blocks)), dim3(kXBlock), lds, c->L().stream, p, kXSlots, c->flushLanes);
+  HIP_OK(c, hipGetLastError());
+  return 0;
+}
+
 int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   LaunchPlan L = plan_launch(c, (size_t)p.slabStride);
   if (L.priv && L.brick) {  // fill_params chose the brick arrays: private tallies give way
     L.priv = false;
     L.gridLds = false;
     L.lds = plan_launch_lds(c, L);
+  }
+  if (exchange_applies(c, L, debug)) {
+    if (L.priv && L.gridLds) return L.tblLds ? launch_trace_x<true, 2>(c, p, L, nBatches) : launch_trace_x<false, 2>(c, p, L, nBatches);
+    if (L.priv) return L.tblLds ? launch_trace_x<true, 1>(c, p, L, nBatches) : launch_trace_x<false, 1>(c, p, L, nBatches);
+    return L.tblLds ? launch_trace_x<true, 0>(c, p, L, nBatches) : launch_trace_x<false, 0>(c, p, L, nBatches);
   }
   if (L.block == 512) return debug ? launch_trace_b<512, true>(c, p, L, nBatches) : launch_trace_b<512, false>(c, p, L, nBatches);
   return debug ? launch_trace_b<256, true>(c, p, L, nBatches) : launch_trace_b<256, false>(c, p, L, nBatches);
@@ -560,9 +603,14 @@ mcbrat_ctx *mcbrat_create(int device) {
   c->device = device;
   if (const char *e = getenv("MCBRAT_REGULAR_WALK")) c->regularWalk = atoi(e);
   if (const char *e = getenv("MCBRAT_LAYER_SKIP")) c->layerSkip = atoi(e);
+  if (const char *e = getenv("MCBRAT_EXCHANGE")) c->exchangeMode = atoi(e);
+  if (const char *e = getenv("MCBRAT_FLUSH_LANES")) c->flushLanes = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_TUNE_PHOTONS")) c->tuneTrialPhotons = strtoull(e, nullptr, 10);
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCUs = prop.multiProcessorCount;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    c->numCUs = prop.multiProcessorCount;
+    if (prop.maxSharedMemoryPerMultiProcessor > 0) c->ldsPerCU = prop.maxSharedMemoryPerMultiProcessor;
+  }
   if (init_lane(c, 0) || hipEventCreateWithFlags(&c->evExternal, hipEventDisableTiming) != hipSuccess ||
       hipMalloc((void **)&c->dEventCounters, 32 * sizeof(unsigned long long)) != hipSuccess) {
     delete c;
@@ -948,9 +996,10 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   return 0;
 }
 
-int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip) {
+int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip, int32_t exchange) {
   if (!c) return 1;
   if (layerSkip >= 0) { if ((layerSkip != 0) != (c->layerSkip != 0)) c->tuned = false; c->layerSkip = layerSkip ? 1 : 0; }
+  if (exchange >= 0) { if ((exchange != 0) != (c->exchangeMode != 0)) c->tuned = false; c->exchangeMode = exchange ? 1 : 0; }
   return 0;
 }
 

@@ -180,11 +180,11 @@ class Integrator:
         return int(self.intensityMus.size) if self.computeIntensity else 0
 
     def setTuning(self, blocksPerCU=-1, eventThreshold=0, maxBatchesInFlight=-1, privateTallies=-1, blockSize=-1,
-                  launchThreshold=0, surfaceThreshold=0, brickLayout=-1, layerSkip=-1):
+                  launchThreshold=0, surfaceThreshold=0, brickLayout=-1, layerSkip=-1, exchange=-1):
         self._check(self._lib.mcbrat_set_tuning(self._ctx, blocksPerCU, eventThreshold, maxBatchesInFlight,
                                                 privateTallies, blockSize, launchThreshold, surfaceThreshold, brickLayout))
-        if layerSkip >= 0:
-            self._check(self._lib.mcbrat_set_walk_options(self._ctx, int(layerSkip)))
+        if layerSkip >= 0 or exchange >= 0:
+            self._check(self._lib.mcbrat_set_walk_options(self._ctx, int(layerSkip), int(exchange)))
 
     def eventThreshold(self):
         return int(self._lib.mcbrat_get_event_threshold(self._ctx))
