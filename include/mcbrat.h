@@ -191,9 +191,10 @@ int mcbrat_set_tuning(mcbrat_ctx *ctx, int32_t blocksPerCU, int32_t eventThresho
  * accumulateExtinctionAlongPath (src/opticalProperties.f95:1697-1814) stops at every x and y face too, which changes
  * nothing inside such a layer but the float rounding of the accumulated optical depth; 0 restores that face-by-face
  * walk (used by the per-photon identity tests).
- * exchange (default 1): flux runs with the directional source use the photon-exchange form of the tracing kernel
- * (photons move between waves at leg boundaries through LDS queues, so that walking and event processing both run
- * with nearly all lanes busy); results are bitwise those of the one-photon-per-lane kernel, which 0 selects. */
+ * exchange (default 0, experimental): flux runs with the directional source use the photon-exchange form of the
+ * tracing kernel (mcbrat_exchange.hip: photons move between waves at leg boundaries through LDS queues, so that
+ * walking and event processing both run with nearly all lanes busy).  Results are bitwise those of the
+ * one-photon-per-lane kernel; it is not faster on the workloads measured so far. */
 int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t exchange);
 
 /* The event threshold in use (after the first call of a domain: the one chosen by the trial launches). */

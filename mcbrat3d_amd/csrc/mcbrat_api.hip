@@ -109,7 +109,7 @@ struct mcbrat_ctx {
   unsigned long long tuneTrialPhotons = 1ull << 24;  // MCBRAT_TUNE_PHOTONS
   int regularWalk = 1;         // equally spaced grids: incremental face distances (MCBRAT_REGULAR_WALK=0 turns it off)
   int gridLdsMode = 1;         // stage the optical grid in LDS when it fits (private-tally mode)
-  int exchangeMode = 1;        // photon-exchange form of the tracing kernel where it applies (MCBRAT_EXCHANGE=0 / mcbrat_set_walk_options)
+  int exchangeMode = 0;        // photon-exchange form of the tracing kernel where it applies: opt-in (MCBRAT_EXCHANGE=1 / mcbrat_set_walk_options), see DESIGN.md
   int flushLanes = 16;         // exchange kernel: lanes of a wave that have stopped before it hands legs over (MCBRAT_FLUSH_LANES)
   int layerSkip = 1;           // layers of one extinction value: cross z faces only (MCBRAT_LAYER_SKIP=0 / mcbrat_set_walk_options)
   bool countersOn = false;
@@ -497,6 +497,9 @@ constexpr int kXBlock = 512, kXSlots = 704;
 size_t exchange_lds(const LaunchPlan &L) { return ((L.lds + 15) & ~(size_t)15) + 32 + 3 * kXCells * sizeof(unsigned) + (size_t)kXSlots * 80; }
 
 bool exchange_applies(const mcbrat_ctx *c, const LaunchPlan &L, bool debug) {
+#ifdef MCBRAT_XSTATS
+  debug = false;  // (the stats build reports through the counters of an instrumented call)
+#endif
   return c->exchangeMode != 0 && !debug && c->nDir == 0 && !L.brick && c->srcKind == 0 && !(c->lwFlag > 0.f) &&
          c->nx <= 1024 && c->ny <= 1024 && c->nz <= 1024 && exchange_lds(L) <= (size_t)c->ldsPerCU;
 }
@@ -1111,6 +1114,19 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   if (c->countersOn) {
     unsigned long long h[16];
     HIP_OK(c, hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost));
+#ifdef MCBRAT_XSTATS  // development aid: the exchange kernel's sections
+    if (c->exchangeMode) {
+      unsigned long long st[16];
+      HIP_OK(c, hipMemcpy(st, c->dEventCounters + 16, sizeof(st), hipMemcpyDeviceToHost));
+      const char *names[6] = {"refill", "walk", "flush", "event pass", "launch pass", "idle"};
+      double tot = 0;
+      for (int i = 0; i < 6; i++) tot += (double)st[i];
+      for (int i = 0; i < 6; i++) fprintf(stderr, "xstat %-12s %14llu  %5.1f %%\n", names[i], st[i], 100.0 * (double)st[i] / tot);
+      fprintf(stderr, "xstat walk iterations %llu, lanes/iteration %.1f | flushes %llu, lanes/flush %.1f | event passes %llu, lanes/pass %.1f | launch passes %llu, lanes/pass %.1f\n",
+              st[6], (double)st[7] / (double)std::max(1ull, st[6]), st[8], (double)st[9] / (double)std::max(1ull, st[8]), st[10],
+              (double)st[11] / (double)std::max(1ull, st[10]), st[12], (double)st[13] / (double)std::max(1ull, st[12]));
+    }
+#endif
 #ifdef MCBRAT_STAMPS  // development aid: wave cycles per section of the tracing loop
     {
       unsigned long long st[16];

@@ -20,6 +20,16 @@
 // no radiance, no instrumentation; everything else stays with trace_kernel.
 #include "mcbrat_device.h"
 
+// Development aid: -DMCBRAT_XSTATS makes every wave report cycles per section (refill, walk, flush, event pass, launch
+// pass, idle) and how many lanes each kind of pass served, through DevParams::counters (slots 16..).
+#ifdef MCBRAT_XSTATS
+#define XSTAMP(i) do { const unsigned long long t_ = clock64(); xs[i] += t_ - xt; xt = t_; } while (0)
+#define XCOUNT(i, v) do { xs[i] += (unsigned long long)(v); } while (0)
+#else
+#define XSTAMP(i) do { } while (0)
+#define XCOUNT(i, v) do { } while (0)
+#endif
+
 namespace mcbrat {
 
 constexpr int kXCells = 1024;  // cells per ring (a power of two, more than the slots of a workgroup)
@@ -201,6 +211,9 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
     if (state == ST_ENTER) { extCur = p.ext[cell]; state = ST_WALK; }
   };
 
+#ifdef MCBRAT_XSTATS
+  unsigned long long xs[16] = {0}, xt = clock64();
+#endif
   for (unsigned long long unit = blockIdx.x;; unit += gridDim.x) {
     if (PRIV) {  // workgroup-uniform: this workgroup's unit = photons [unitFirst, unitFirst + unitCount) of ONE batch
       if (unit >= p.nUnits) break;
@@ -222,6 +235,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
 
     for (;;) {
       bool worked = false;
+      XSTAMP(5);
       // ================= walking lanes: take waiting legs =================================================
       {
         const int nIdle = __popcll(__ballot(state == ST_DEAD));
@@ -262,6 +276,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           }
         }
       }
+      XSTAMP(0);
       // ================= walk: one voxel face per iteration (trace_kernel's loop) =========================
       {
         const int nStart = __popcll(__ballot(state == ST_WALK));
@@ -270,6 +285,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           const int stopBelow = max(nStart - flushLanes + 1, 1);  // until flushLanes lanes have stopped, or all
           int nWalk = nStart;
           while (nWalk >= stopBelow) {
+            XCOUNT(6, 1); XCOUNT(7, nWalk);
             if (state == ST_WALK) {
               const bool yLtX = tny < tnx;
               const float m2 = yLtX ? tny : tnx;
@@ -321,6 +337,8 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
             }
             nWalk = __popcll(__ballot(state == ST_WALK));
           }
+          XSTAMP(1);
+          XCOUNT(8, 1); XCOUNT(9, __popcll(__ballot(state != ST_WALK && state != ST_DEAD)));
           // ---- lanes that stopped: runs of one-extinction layers, then hand finished legs over ----
           if (LAZY) {
             if (state == ST_JUMP) tryJump();
@@ -360,6 +378,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           if (state == ST_COLLIDE || state == ST_SURFACE || state == ST_TOP) state = ST_DEAD;
         }
       }
+      XSTAMP(2);
       const bool starving = __ballot(state != ST_DEAD) == 0ull && xq_count(s_qctl + XQ_WALK) <= 0;
       // ================= a dense pass over 64 collisions / surface hits ===================================
       const int cntE = xq_count(s_qctl + XQ_EVENT);
@@ -367,6 +386,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         const int es = xq_pop(s_qctl + XQ_EVENT, qEvent, true, starving ? 1 : kWave, lane, laneBelow);
         if (__ballot(es >= 0) != 0ull) {
           worked = true;
+          XCOUNT(10, 1); XCOUNT(11, __popcll(__ballot(es >= 0)));
           bool alive = false;
           if (es >= 0) {
             const uint4 q0 = s_pool[5 * es], q1 = s_pool[5 * es + 1], q2 = s_pool[5 * es + 2], q3 = s_pool[5 * es + 3], q4 = s_pool[5 * es + 4];
@@ -498,6 +518,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           xq_push(s_qctl + XQ_DEAD, qDead, es >= 0 && !alive, (unsigned)es, lane, laneBelow);
         }
       }
+      XSTAMP(3);
       // ================= 64 dead slots: new photons (getNextPhoton + computeRT :466-508) ===================
       const int cntD = xq_count(s_qctl + XQ_DEAD);
       if (cntD >= kWave || (starving && cntD > 0 && cntE <= 0)) {
@@ -505,6 +526,7 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
         const unsigned long long mHave = __ballot(ds >= 0);
         if (mHave != 0ull) {
           worked = true;
+          XCOUNT(12, 1); XCOUNT(13, __popcll(mHave));
           const int nHave = __popcll(mHave), rank = __popcll(mHave & laneBelow);
           unsigned long long myIdx;
           bool valid;
@@ -565,12 +587,14 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
           if (nRetire > 0 && lane == 0) atomicSub(&s_qctl[XQ_LIVE], (unsigned)nRetire);
         }
       }
+      XSTAMP(4);
       if (x_load_uniform(&s_qctl[XQ_LIVE]) == 0u) break;  // every slot is out of use: nothing is in flight anywhere
       if (!worked) __builtin_amdgcn_s_sleep(8);
     }
 
     if (!PRIV) break;
     __syncthreads();
+    XSTAMP(5);
     for (int i = threadIdx.x; i < slabLen; i += BLOCK) {
       const long long v = s_slab[i];
       if (v != 0) {
@@ -581,6 +605,9 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
     if (threadIdx.x == 0) s_cursor[0] = 0;
     __syncthreads();
   }
+#ifdef MCBRAT_XSTATS
+  if (p.counters && lane == 0) for (int i = 0; i < 14; i++) atomicAdd(p.counters + 16 + i, xs[i]);
+#endif
 }
 
 }  // namespace mcbrat
