@@ -26,7 +26,8 @@ module mcbrat_hip_integrator
             specifyParameters, computeRadiativeTransfer, reportResults, &
             resetMoments, getMoments, momentsLength, lastMessage, &
             inverseTableLegendre, lastTraceMilliseconds, setAsynchronous, synchronize, &
-            specifyIntensity, setForwardTable, reportIntensity, forwardTableLegendre
+            specifyIntensity, setForwardTable, reportIntensity, forwardTableLegendre, &
+            setSurfaceDescription
 
   interface
     function mcbrat_create(device) bind(C, name="mcbrat_create") result(ctx)
@@ -71,6 +72,15 @@ module mcbrat_hip_integrator
       type(c_ptr), value :: ctx
       integer(c_int32_t), value :: rayTracing, roulette
       real(c_float), value :: lwFlag
+      integer(c_int) :: rc
+    end function
+    function mcbrat_set_surface_description(ctx, numX, numY, xPosition, yPosition, reflectance) &
+        bind(C, name="mcbrat_set_surface_description") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_double, c_float
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: numX, numY
+      real(c_double), dimension(*), intent(in) :: xPosition, yPosition
+      real(c_float), dimension(*), intent(in) :: reflectance
       integer(c_int) :: rc
     end function
     function mcbrat_set_source_solar(ctx, mu, azimuth) bind(C, name="mcbrat_set_source_solar") result(rc)
@@ -240,6 +250,21 @@ contains
     ierr = mcbrat_set_inverse_table(this%ctx, int(component, c_int32_t), int(size(values, 1), c_int32_t), &
                                     int(size(values, 2), c_int32_t), values)
   end subroutine setInverseTable
+  !------------------------------------------------------------------------------------------
+  ! specifyParameters(surfaceBDRF = new_SurfaceDescription(surfaceParameters, xPosition, yPosition))
+  ! (monteCarloRadiativeTransfer.f95:1173-1176): reflectance = surfaceParameters(1, :, :)
+  subroutine setSurfaceDescription(this, reflectance, xPosition, yPosition, ierr)
+    type(integrator),      intent(inout) :: this
+    real, dimension(:,:),  intent(in)    :: reflectance
+    real(8), dimension(:), intent(in)    :: xPosition, yPosition
+    integer,               intent(out)   :: ierr
+    if (size(reflectance, 1) /= size(xPosition) - 1 .or. size(reflectance, 2) /= size(yPosition) - 1) then
+      ierr = 2   ! "new_SurfaceDescription: position vector(s) are incorrect length."
+      return
+    end if
+    ierr = mcbrat_set_surface_description(this%ctx, int(size(xPosition), c_int32_t), int(size(yPosition), c_int32_t), &
+                                          xPosition, yPosition, reflectance)
+  end subroutine setSurfaceDescription
   !------------------------------------------------------------------------------------------
   subroutine setSolarSource(this, solarMu, solarAzimuth, ierr)   ! new_PhotonStream, Directional
     type(integrator), intent(inout) :: this

@@ -184,6 +184,16 @@ int mcbrat_set_tuning(mcbrat_ctx *ctx, int32_t blocksPerCU, int32_t eventThresho
                       int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold,
                       int32_t brickLayout);
 
+/* specifyParameters(surfaceBDRF = new_SurfaceDescription(surfaceParameters, xPosition, yPosition))
+ * (Integrators/monteCarloRadiativeTransfer.f95:1173-1176, src/surfaceProperties.f95:58-94): a reflecting surface whose
+ * Lambertian reflectance varies from patch to patch on its own horizontal positions (numX x-positions bound numX-1
+ * patches; `reflectance` is BRDFParameters(1, :, :), x fastest).  A photon that reaches the surface is multiplied by
+ * the reflectance of the patch under it (computeSurfaceReflectance :119-147) instead of the domain's albedo
+ * (computeRT :667-673).  The uniform surface of newSurfaceUniform is numX = numY = 2 with positions (0, huge(1.)).
+ * numX <= 0 returns to the domain's albedo.  Error texts are the reference's. */
+int mcbrat_set_surface_description(mcbrat_ctx *ctx, int32_t numX, int32_t numY, const double *xPosition,
+                                   const double *yPosition, const float *reflectance);
+
 /* Walk options (negative = leave unchanged).
  * layerSkip (default 1): inside a horizontal layer whose cells all carry one extinction value -- the clear air
  * above and below a cloud field -- a photon crosses z faces only; its column is found again from its position when

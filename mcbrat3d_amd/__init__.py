@@ -7,6 +7,7 @@ include/mcbrat.h and hand-written HIP kernels for gfx950:
     opticalProperties        -> mcbrat3d_amd.domain      (Domain, addOpticalComponent, ...)
     monteCarloIllumination   -> mcbrat3d_amd.illumination (PhotonStream)
     emissionAndBBWeights     -> mcbrat3d_amd.illumination (Weights, emission_weighting)
+    surfaceProperties        -> mcbrat3d_amd.surface     (SurfaceDescription)
     monteCarloRadiativeTransfer -> mcbrat3d_amd.integrator (Integrator)
     monteCarloDriver worker loop + statistics -> mcbrat3d_amd.driver
 """
@@ -15,3 +16,4 @@ from .phase import PhaseFunction, PhaseFunctionTable, new_PhaseFunction, new_Pha
 from .domain import Domain, new_Domain  # noqa: F401
 from .illumination import PhotonStream, Weights, new_PhotonStream, new_Weights, emission_weighting  # noqa: F401
 from .integrator import Integrator, new_Integrator  # noqa: F401
+from .surface import SurfaceDescription, new_SurfaceDescription  # noqa: F401

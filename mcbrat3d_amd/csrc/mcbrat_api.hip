@@ -67,6 +67,10 @@ struct mcbrat_ctx {
   bool bricksBuilt = false;
   int brickMode = 2;               // 0 dense, 1 bricks, 2 automatic
   float *dTables = nullptr;
+  // surface description (specifyParameters(surfaceBDRF=)); surfNumX == 0: the domain's albedo
+  int surfNumX = 0, surfNumY = 0;
+  double *dSurfX = nullptr, *dSurfY = nullptr;
+  float *dSurfRefl = nullptr;
   double *dVoxelCDF = nullptr;
   unsigned long long *dEventCounters = nullptr;
   float *dLast = nullptr;
@@ -387,6 +391,7 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
     p.rec = reinterpret_cast<const uint4 *>(c->dRec);
   }
   p.albedo = c->albedo;
+  p.surfNumX = c->surfNumX; p.surfNumY = c->surfNumY; p.surfX = c->dSurfX; p.surfY = c->dSurfY; p.surfRefl = c->dSurfRefl;
   p.tables = c->dTables;
   for (int k = 0; k < c->nc; ++k) { p.tblOffset[k] = c->tblOffset[k]; p.tblNSteps[k] = c->tblNSteps[k]; p.tblInvN[k] = 1.0f / (float)c->tblNSteps[k]; }
   p.tblTotalFloats = c->tblTotalFloats;
@@ -500,7 +505,7 @@ bool exchange_applies(const mcbrat_ctx *c, const LaunchPlan &L, bool debug) {
 #ifdef MCBRAT_XSTATS
   debug = false;  // (the stats build reports through the counters of an instrumented call)
 #endif
-  return c->exchangeMode != 0 && !debug && c->nDir == 0 && !L.brick && c->srcKind == 0 && !(c->lwFlag > 0.f) &&
+  return c->exchangeMode != 0 && !debug && c->nDir == 0 && c->surfNumX == 0 && !L.brick && c->srcKind == 0 && !(c->lwFlag > 0.f) &&
          c->nx <= 1024 && c->ny <= 1024 && c->nz <= 1024 && exchange_lds(L) <= (size_t)c->ldsPerCU;
 }
 
@@ -628,7 +633,7 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   (void)sync_all(c);
   void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF,
                   c->dEventCounters, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
-                  c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT};
+                  c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dSurfX, c->dSurfY, c->dSurfRefl};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (mcbrat_ctx::Lane &L : c->lane) {
     void *lb[] = {L.dCounter, L.dSlabs, L.dColVals, L.dScalVals};
@@ -996,6 +1001,26 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   if (launchThreshold > 0) c->launchThreshold = launchThreshold;
   if (surfaceThreshold > 0) c->surfaceThreshold = surfaceThreshold;
   if (brickLayout >= 0 && brickLayout <= 2) { if (brickLayout != c->brickMode) c->tuned = false; c->brickMode = brickLayout; }
+  return 0;
+}
+
+int mcbrat_set_surface_description(mcbrat_ctx *c, int32_t numX, int32_t numY, const double *xPosition, const double *yPosition,
+                                   const float *reflectance) {
+  if (!c) return 1;
+  (void)hipSetDevice(c->device);
+  if (sync_all(c)) return 1;
+  if (numX <= 0 || numY <= 0) { c->surfNumX = c->surfNumY = 0; return 0; }  // back to the domain's albedo
+  // the checks of newSurfaceDescriptionXY, src/surfaceProperties.f95:66-82
+  if (numX < 2 || numY < 2 || !xPosition || !yPosition || !reflectance)
+    return fail(c, "new_SurfaceDescription: position vector(s) are incorrect length.");
+  for (int i = 1; i < numX; ++i) if (!(xPosition[i] - xPosition[i - 1] > 0.)) return fail(c, "new_SurfaceDescription: positions must be unique, increasing.");
+  for (int i = 1; i < numY; ++i) if (!(yPosition[i] - yPosition[i - 1] > 0.)) return fail(c, "new_SurfaceDescription: positions must be unique, increasing.");
+  for (size_t i = 0; i < (size_t)(numX - 1) * (numY - 1); ++i)
+    if (!(reflectance[i] >= 0.f && reflectance[i] <= 1.f)) return fail(c, "new_SurfaceDescription: surface reflectance must be between 0 and 1");
+  if (upload(c, &c->dSurfX, xPosition, (size_t)numX) || upload(c, &c->dSurfY, yPosition, (size_t)numY) ||
+      upload(c, &c->dSurfRefl, reflectance, (size_t)(numX - 1) * (numY - 1)))
+    return 1;
+  c->surfNumX = numX; c->surfNumY = numY;
   return 0;
 }
 

@@ -42,6 +42,11 @@ struct DevParams {
   const uint16_t *pfi;            // [nc][nvox] 0-based entry
   const uint4 *rec;               // dense layout, nc <= 2: per cell {cum[0], ssa[0], ssa[1], pfi[0] | pfi[1] << 16}, else null
   float albedo;
+  // surfaceDescription (specifyParameters(surfaceBDRF=), src/surfaceProperties.f95): reflectance per surface patch on its
+  // own x/y positions; surfNumX == 0: the domain's Lambertian albedo
+  int surfNumX, surfNumY;
+  const double *surfX, *surfY;
+  const float *surfRefl;          // [numY-1][numX-1]
   // brick layout of the optics (large, mostly-background domains): ext/cum/ssa/pfi then hold the
   // STORED bricks only (64 cells each, [component][nStored]); background cells use bg* [component][nz]
   const uint32_t *brickTable;     // [nbz][nby][nbx] offset of the brick's 64 cells, 0xffffffff = background

@@ -143,8 +143,13 @@ class Integrator:
             self.limitIntensityContributions = bool(limitIntensityContributions)
         if maxIntensityContribution is not None and maxIntensityContribution > 0.0:
             self.maxIntensityContribution = float(maxIntensityContribution)
-        if surfaceBDRF is not None:
-            raise McbratError("specifyParameters: only the Lambertian surface is supported")
+        if surfaceBDRF is not None:  # :1091-1094, :1173-1176
+            if not (hasattr(surfaceBDRF, "isReady_surfaceDescription") and surfaceBDRF.isReady_surfaceDescription()):
+                raise McbratError("specifyParameters: surface description isn't valid.")
+            x, y = surfaceBDRF.xPosition, surfaceBDRF.yPosition
+            refl = np.ascontiguousarray(surfaceBDRF.BRDFParameters[0].T, np.float32)  # x fastest
+            self._check(self._lib.mcbrat_set_surface_description(self._ctx, int(x.size), int(y.size), ptr(x), ptr(y), ptr(refl)))
+            self.useSurfaceBDRF = True
         for k, v in unsupported.items():
             if v not in (None, False):
                 raise McbratError("specifyParameters: keyword %s is not supported by the MI355X integrator" % k)

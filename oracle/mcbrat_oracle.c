@@ -274,6 +274,32 @@ int orc_find_index_mixed(float vf, const double *t, int n, int firstGuess) { /* 
   FIND_INDEX_BODY(T1)
 #undef T1
 }
+
+/* makePeriodic, src/surfaceProperties.f95:211-230 (result kind is default real: the position is rounded to float) */
+static float make_periodic(double a, double aMin, double aMax) {
+  float r = (float)a;
+  for (;;) {
+    if ((double)r <= aMax && (double)r > aMin) break;
+    if ((double)r > aMax) r = (float)((double)r - (aMax - aMin));
+    else if ((double)r == aMin) r = (float)aMax;
+    else r = (float)((double)r + (aMax - aMin));
+  }
+  return r;
+}
+
+/* computeSurfaceReflectance, src/surfaceProperties.f95:119-147, with R = BRDFParameters(1) (:153-161).  A position
+ * exactly on the lower edge is sent to the upper one (:224-225), where findIndex answers size(xPosition): one past
+ * the last patch in the reference; the last patch here. */
+static float surface_reflectance(const orc_problem *P, double xPos, double yPos) {
+  const int nX = P->surfNumX, nY = P->surfNumY;
+  int xi = orc_find_index_mixed(make_periodic(xPos, P->surfXPosition[0], P->surfXPosition[nX - 1]), P->surfXPosition, nX, 0);
+  int yi = orc_find_index_mixed(make_periodic(yPos, P->surfYPosition[0], P->surfYPosition[nY - 1]), P->surfYPosition, nY, 0);
+  if (xi < 1) xi = 1;
+  if (xi > nX - 1) xi = nX - 1;
+  if (yi < 1) yi = 1;
+  if (yi > nY - 1) yi = nY - 1;
+  return P->surfReflectance[(size_t)(xi - 1) + (size_t)(nX - 1) * (yi - 1)];
+}
 int orc_find_cdf_index(float vf, const double *t, int n) { /* :317-348 */
   double v = (double)vf;
   int lowerBound = 0, upperBound = n, midPoint;
@@ -980,7 +1006,10 @@ int64_t orc_compute_rt_intensity(const orc_problem *P, const orc_source *S, orc_
         }
         phi = (2.0f * Pi) * draw(R, 0, 2);
         float wBefore = photonWeight;
-        photonWeight = (float)((double)photonWeight * albedo); /* :673 */
+        if (P->surfNumX > 0) /* useSurfaceBDRF :667-670 (incoming / outgoing angles are not used by the reference's R) */
+          photonWeight = photonWeight * surface_reflectance(P, xPos, yPos);
+        else
+          photonWeight = (float)((double)photonWeight * albedo); /* :673 */
         if (photonWeight <= FLT_MIN) { cnt.surfaceAbsorbed++; fate = 1; fateWeight = wBefore; break; }
         if (R->mode == 1) { /* Philox mode: cos / sin of 2 pi Y by the kernel's expression (sincos_2pi), as in next_direct */
           float sinTheta = sqrtf(1.0f - mu * mu), c, s;

@@ -44,6 +44,11 @@ typedef struct {
   const int32_t *invNEntries;        /* [nc] entries                          */
   int32_t useRussianRoulette;
   float lwFlag;                      /* > 0: thermal emission bookkeeping     */
+  /* surfaceDescription (src/surfaceProperties.f95:33-36), set by specifyParameters(surfaceBDRF=)
+   * (monteCarloRadiativeTransfer.f95:1173-1176); surfNumX == 0: the domain's Lambertian albedo is used */
+  int32_t surfNumX, surfNumY;        /* size(xPosition), size(yPosition)      */
+  const double *surfXPosition, *surfYPosition;
+  const float *surfReflectance;      /* BRDFParameters(1, :, :): [numY-1][numX-1], x fastest */
 } orc_problem;
 
 /* Photon source (src/monteCarloIllumination.f95). */

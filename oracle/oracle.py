@@ -30,6 +30,8 @@ class OrcProblem(C.Structure):
         ("invNSteps", C.c_void_p), ("invNEntries", C.c_void_p),
         ("useRussianRoulette", C.c_int32),
         ("lwFlag", C.c_float),
+        ("surfNumX", C.c_int32), ("surfNumY", C.c_int32),
+        ("surfXPosition", C.c_void_p), ("surfYPosition", C.c_void_p), ("surfReflectance", C.c_void_p),
     ]
 
 
@@ -249,7 +251,7 @@ class Problem:
     """Owns the numpy arrays behind an OrcProblem."""
 
     def __init__(self, xe, ye, ze, totalExt, cumExt, ssa, pfIndex, albedo, inv_tables,
-                 use_russian_roulette=True, lw_flag=-1.0):
+                 use_russian_roulette=True, lw_flag=-1.0, surface=None):
         self.xe = np.ascontiguousarray(xe, np.float64)
         self.ye = np.ascontiguousarray(ye, np.float64)
         self.ze = np.ascontiguousarray(ze, np.float64)
@@ -277,7 +279,21 @@ class Problem:
         self.c = OrcProblem(self.nx, self.ny, self.nz, self.nc, _p(self.xe), _p(self.ye), _p(self.ze),
                             _p(self.totalExt), _p(self.cumExt), _p(self.ssa), _p(self.pfIndex),
                             self.albedo, _p(self.invTables), _p(self.invOffset), _p(self.invNSteps),
-                            _p(self.invNEntries), 1 if use_russian_roulette else 0, float(lw_flag))
+                            _p(self.invNEntries), 1 if use_russian_roulette else 0, float(lw_flag),
+                            0, 0, None, None, None)
+        if surface is not None:
+            self.set_surface(*surface)
+
+    def set_surface(self, reflectance, x_position, y_position):
+        """specifyParameters(surfaceBDRF = new_SurfaceDescription(reflectance, xPosition, yPosition)):
+        reflectance[numX-1, numY-1] (Fortran index order), positions increasing."""
+        self.surfX = np.ascontiguousarray(x_position, np.float64)
+        self.surfY = np.ascontiguousarray(y_position, np.float64)
+        r = np.asarray(reflectance, np.float32)
+        assert r.shape == (self.surfX.size - 1, self.surfY.size - 1)
+        self.surfR = np.ascontiguousarray(r.T).reshape(-1)  # x fastest
+        self.c.surfNumX, self.c.surfNumY = self.surfX.size, self.surfY.size
+        self.c.surfXPosition, self.c.surfYPosition, self.c.surfReflectance = _p(self.surfX), _p(self.surfY), _p(self.surfR)
 
     def grid_flags(self):
         a, b = C.c_int(), C.c_int()

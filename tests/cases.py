@@ -121,8 +121,9 @@ def oracle_problem(case, nsteps=10001, use_russian_roulette=True, lw_flag=-1.0):
                                     for a, v in comp["tabulated"]]))
         else:
             tables.append(np.stack([O.inverse_table_legendre(c, nsteps) for c in comp["legendre"]]))
+    # case["surface"] = (reflectance[numX-1, numY-1], xPosition, yPosition): specifyParameters(surfaceBDRF=)
     return O.Problem(case["xe"], case["ye"], case["ze"], tot, cum, ssa, pfi, case["albedo"], tables,
-                     use_russian_roulette=use_russian_roulette, lw_flag=lw_flag)
+                     use_russian_roulette=use_russian_roulette, lw_flag=lw_flag, surface=case.get("surface"))
 
 
 def oracle_intensity(case, mus, phis_deg, n_angles=9001, hybrid_width=None, **kw):
@@ -157,6 +158,30 @@ def product_domain(case):
                                 zLevelBase=comp.get("zLevelBase", 1))
     dom.getOpticalPropertiesByComponent()
     return dom
+
+
+def product_surface(case):
+    """The case's surface description for the PRODUCT (None: the domain's albedo)."""
+    import mcbrat3d_amd as M
+    if case.get("surface") is None:
+        return None
+    refl, x, y = case["surface"]
+    return M.new_SurfaceDescription(np.asarray(refl, np.float32)[None], x, y)
+
+
+def patchy_surface(case, nxs=5, nys=3, seed=8):
+    """A copy of the case with a reflecting surface of nxs x nys patches (reflectances 0 .. 0.9, one of them black)
+    on positions of its own that span the domain."""
+    rng = np.random.default_rng(seed)
+    out = dict(case)
+    x = np.linspace(case["xe"][0], case["xe"][-1], nxs + 1)
+    y = np.linspace(case["ye"][0], case["ye"][-1], nys + 1)
+    x[1:-1] += rng.uniform(-0.3, 0.3, nxs - 1) * (x[1] - x[0])
+    y[1:-1] += rng.uniform(-0.3, 0.3, nys - 1) * (y[1] - y[0])
+    refl = rng.uniform(0.05, 0.9, (nxs, nys)).astype(np.float32)
+    refl[0, 0] = 0.0
+    out["surface"] = (refl, x, y)
+    return out
 
 
 def radar_like(n=128, nz=64, seed=20240602):

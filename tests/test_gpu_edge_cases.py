@@ -198,3 +198,38 @@ def test_async_calls_overlap_and_match_synchronous_mode(M):
     assert ka > 0.0
     print("40 per-batch calls: synchronous %.1f ms, asynchronous %.1f ms (kernel time %.1f / %.1f ms)" % (ts * 1e3, ta * 1e3, ks, ka))
     assert ta < 1.5 * ts  # normally about half (the drain of one call overlaps the next); loose: wall clocks on a shared box
+
+
+def test_surface_description_patches(M):
+    """specifyParameters(surfaceBDRF=): a reflecting surface of 5 x 3 patches (one of them black) on positions that
+    differ from the grid's, under the step cloud and under a broken cloud field; per-photon fates and the batch's
+    fluxes against the oracle on the same Philox streams, and the domain's own albedo must be ignored."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    from oracle import oracle as O
+    for base, mu0, phi0 in ((cases.step_cloud(0.99), 0.7, 20.0), (cases.landsat_like(n=48, nz=24, n_entries=6), 0.5, 30.0)):
+        case = cases.patchy_surface(base)
+        case["albedo"] = 0.77  # ignored once a surface description is given (computeRT :667-673)
+        n = 30000
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True,
+                                surfaceBDRF=cases.product_surface(case))
+        photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+        got = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+        res = integ.reportResults()
+        integ.finalize()
+        P = cases.oracle_problem(case, nsteps=9001)
+        ref = O.compute_rt(P, O.solar_source(mu0, phi0), O.philox_rng(SEED, 0), n, want_fates=True)
+        rf = ref["fates"]
+        same = (got["fate"] == rf["fate"]) & (got["ix"] == rf["ix"]) & (got["iy"] == rf["iy"]) & \
+            (got["nScatter"] == rf["nScatter"]) & (np.abs(got["weight"] - rf["weight"]) <= 1e-6)
+        assert same.mean() > 0.99, "only %.4f of photon histories identical" % same.mean()
+        assert (rf["fate"] == 1).sum() > 50  # photons that met the black patch
+        mu, md, ma, _ = O.report_means(P, O.normalize(P, n, ref))
+        for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
+            assert abs(g - r) < 3e-3, (g, r)
+    with pytest.raises(M.McbratError, match="surface description isn't valid"):
+        integ2 = M.new_Integrator(cases.product_domain(cases.step_cloud(0.99)))
+        integ2.specifyParameters(surfaceBDRF=object())

@@ -139,3 +139,37 @@ def test_forward_tables_and_hybrid_phase_functions_match_oracle(M):
     assert hyb[0, 0] < ref[0] and np.array_equal(hyb[0, 400:], ref[400:])
     iso = M.new_PhaseFunction(np.zeros(0, np.float32)).forward_table(11)
     assert np.all(iso == 0.5)
+
+
+def test_surface_description_host_checks_and_oracle_uniform_case():
+    """new_SurfaceDescription (src/surfaceProperties.f95:58-115): the reference's checks and texts; and in the
+    oracle a uniform surface description of reflectance 1/4 gives what the domain albedo 1/4 gives (float * float
+    and the reference's double product agree exactly for a power of two), while a black patch map does not."""
+    import mcbrat3d_amd as M
+    from oracle import oracle as O
+    s = M.new_SurfaceDescription([0.25])
+    assert s.isReady_surfaceDescription() and s.BRDFParameters.shape == (1, 1, 1) and s.xPosition[1] > 1e38
+    with pytest.raises(M.McbratError, match="Wrong number of parameters"):
+        M.new_SurfaceDescription([0.1, 0.2])
+    with pytest.raises(M.McbratError, match="incorrect length"):
+        M.new_SurfaceDescription(np.zeros((1, 2, 2), np.float32), [0.0, 1.0], [0.0, 1.0, 2.0])
+    with pytest.raises(M.McbratError, match="unique, increasing"):
+        M.new_SurfaceDescription(np.zeros((1, 2, 1), np.float32), [0.0, 1.0, 1.0], [0.0, 1.0])
+    with pytest.raises(M.McbratError, match="between 0 and 1"):
+        M.new_SurfaceDescription(np.full((1, 1, 1), 1.5, np.float32), [0.0, 1.0], [0.0, 1.0])
+    n = 4000
+    case = cases.step_cloud(ssa=0.99)
+    case["albedo"] = 0.25
+    a = O.compute_radiative_transfer(cases.oracle_problem(case), O.solar_source(0.7, 20.0), O.mt_rng(5), n)
+    huge = float(np.finfo(np.float32).max)
+    case["albedo"] = 0.9  # must be ignored once a surface description is given (:667-673)
+    case["surface"] = (np.full((1, 1), 0.25, np.float32), [0.0, huge], [0.0, huge])
+    b = O.compute_radiative_transfer(cases.oracle_problem(case), O.solar_source(0.7, 20.0), O.mt_rng(5), n)
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert a[k] == b[k], k
+    patchy = cases.patchy_surface(cases.step_cloud(ssa=0.99))
+    c = O.compute_radiative_transfer(cases.oracle_problem(patchy), O.solar_source(0.7, 20.0), O.mt_rng(5), n)
+    assert c["meanFluxUp"] != a["meanFluxUp"]
+    # energy: what goes up, is absorbed in the medium or by the surface patches makes up the incoming unit
+    refl, x, y = patchy["surface"]
+    assert 0.0 < c["meanFluxUp"] + c["meanFluxAbsorbed"] < 1.0
