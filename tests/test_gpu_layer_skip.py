@@ -147,3 +147,46 @@ def test_irregular_columns_with_clear_runs(M):
     short = fates[0]["nScatter"] <= 3
     assert _same(fates[1], fates[0])[short].mean() > 0.995
     assert np.all(np.abs(means[1] - means[0]) < 2.5e-3), (means[1], means[0])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_domains_against_face_by_face_walk(M, seed):
+    """Differential test on random small domains: random grid spacing (equal or stretched), random pattern of
+    one-extinction layers (including none and all), vacuum layers, one or two components, random sun and surface.
+    The layer-skipping walk must give the face-by-face walk's histories (up to the rounding of the optical depth,
+    which can flip a branch for a few photons in 10^4) and the same fluxes within the Monte Carlo error."""
+    rng = np.random.default_rng(1000 + seed)
+    nx, ny, nz = int(rng.integers(1, 9)), int(rng.integers(1, 7)), int(rng.integers(2, 14))
+    def edges(n, stretched):
+        d = rng.uniform(0.02, 0.06) * (np.cumprod(rng.uniform(0.85, 1.2, n)) if stretched else np.ones(n))
+        return np.concatenate([[0.0], np.cumsum(d)]) + (rng.uniform(-1.0, 1.0) if stretched else 0.0)
+    xe, ye, ze = edges(nx, rng.random() < 0.4), edges(ny, rng.random() < 0.4), edges(nz, rng.random() < 0.5)
+    ze -= ze[0]
+    ext = rng.uniform(0.0, 25.0, (nx, ny, nz))
+    uniform = rng.random(nz) < rng.choice([0.0, 0.5, 0.8, 1.0])
+    for k in np.nonzero(uniform)[0]:
+        ext[:, :, k] = rng.choice([0.0, rng.uniform(0.01, 8.0)])
+    comps = [dict(ext=ext, ssa=np.where(ext > 0, rng.uniform(0.6, 1.0), 0.0), pfIndex=np.ones(ext.shape, np.int32),
+                  legendre=[cases.hg_legendre(rng.uniform(0.0, 0.9), 24)])]
+    if rng.random() < 0.5:
+        comps.append(dict(ext=rng.uniform(0.0, 0.3, nz), ssa=np.ones(nz), pfIndex=np.ones(nz, np.int32),
+                          legendre=[np.array([0.0, 0.1], np.float32)]))
+    case = dict(name="random%d" % seed, xe=xe, ye=ye, ze=ze, albedo=float(rng.choice([0.0, 0.3, 0.8])), components=comps)
+    mu0, phi0 = float(rng.choice([1.0, rng.uniform(0.05, 1.0)])), float(rng.uniform(0.0, 360.0))
+    n = 20000
+    fates, means = {}, {}
+    for skip in (0, 1):
+        dom, integ, photons, r = _integ(M, case, mu0, phi0, skip, rr=bool(rng.integers(0, 2)) if skip == 0 else rr_used)
+        rr_used = integ.useRussianRoulette
+        fates[skip] = integ.traceFates(dom, r, photons, n)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, r, photons, n)
+        res = integ.reportResults()
+        means[skip] = np.array([res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"]])
+        integ.finalize()
+    same = _same(fates[1], fates[0])
+    assert same.mean() > 0.97, (case["name"], nx, ny, nz, same.mean())
+    assert same[fates[0]["nScatter"] <= 2].mean() > 0.995
+    assert np.all(np.abs(means[1] - means[0]) < 4e-3), (means[1], means[0])
+    a = case["albedo"]
+    assert abs(means[1][0] + means[1][2] + (1.0 - a) * means[1][1] - 1.0) < 4.0 / np.sqrt(n)
