@@ -177,7 +177,7 @@ int mcbrat_wait_stream(mcbrat_ctx *ctx, void *hipStream);
 /* Tuning knobs (negative = leave unchanged): workgroups per CU (0 = occupancy query), number of
  * walking lanes below which a wave serves its waiting lanes (0 = choose by timing short trial
  * launches, the default), batches in flight per launch
- * (0 = memory bound), LDS-private tallies on/off, workgroup size (0 = automatic, 256, 512), and how
+ * (0 = memory bound), LDS-private tallies on/off, workgroup size (0 = automatic, 256, 512, 768), and how
  * many idle / surface lanes queue up before launches / surface reflections are served; brickLayout:
  * 0 dense optical grids, 1 4x4x4 bricks with unstored background bricks, 2 automatic (default). */
 int mcbrat_set_tuning(mcbrat_ctx *ctx, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight,

@@ -440,7 +440,7 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
   const size_t grid = nvox * 4 + (size_t)c->nc * nvox * (4 + 4) + (((size_t)c->nc * nvox + 1) & ~(size_t)1) * 2;
   L.gridLds = L.priv && c->gridLdsMode != 0 && edges + bg + slab + grid + (L.tblLds ? tbl : 0) <= kLdsBudget;
   L.lds = edges + bg + (L.priv ? slab : 0) + (L.gridLds ? grid : 0) + (L.tblLds ? tbl : 0);
-  L.block = c->blockSize > 0 ? c->blockSize : ((L.tblLds || L.priv) && L.lds > 16 * 1024 ? 512 : 256);
+  L.block = c->blockSize > 0 ? c->blockSize : (L.gridLds ? 768 : ((L.tblLds || L.priv) && L.lds > 16 * 1024 ? 512 : 256));
   return L;
 }
 
@@ -546,7 +546,11 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
     if (L.priv) return L.tblLds ? launch_trace_x<true, 1>(c, p, L, nBatches) : launch_trace_x<false, 1>(c, p, L, nBatches);
     return L.tblLds ? launch_trace_x<true, 0>(c, p, L, nBatches) : launch_trace_x<false, 0>(c, p, L, nBatches);
   }
-  if (L.block == 512) return debug ? launch_trace_b<512, true>(c, p, L, nBatches) : launch_trace_b<512, false>(c, p, L, nBatches);
+  // small domains (grid, tables and tallies in LDS): LDS holds two workgroups per CU, and two workgroups of 12 waves
+  // (6 per SIMD, 80 VGPRs) beat two of 8 (4 per SIMD, no spills) by 10 % on the step cloud (640 and 896 lanes lose)
+  if (L.block == 768 && L.priv && L.gridLds && c->nDir == 0 && !debug)
+    return L.tblLds ? launch_trace_t<768, true, 2, false, false>(c, p, L.lds, nBatches) : launch_trace_t<768, false, 2, false, false>(c, p, L.lds, nBatches);
+  if (L.block >= 512) return debug ? launch_trace_b<512, true>(c, p, L, nBatches) : launch_trace_b<512, false>(c, p, L, nBatches);
   return debug ? launch_trace_b<256, true>(c, p, L, nBatches) : launch_trace_b<256, false>(c, p, L, nBatches);
 }
 
@@ -996,8 +1000,8 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   if (eventThreshold == 0) { c->autoTune = true; c->tuned = false; }
   if (maxBatchesInFlight >= 0) c->maxBatchesInFlight = maxBatchesInFlight;
   if (privateTallies >= 0) { c->privMode = privateTallies ? 1 : 0; c->gridLdsMode = privateTallies == 2 ? 0 : 1; }
-  if (blockSize == 0 || blockSize == 256 || blockSize == 512) c->blockSize = blockSize;
-  else if (blockSize > 0) return fail(c, "set_tuning: blockSize must be 0, 256 or 512");
+  if (blockSize == 0 || blockSize == 256 || blockSize == 512 || blockSize == 768) c->blockSize = blockSize;
+  else if (blockSize > 0) return fail(c, "set_tuning: blockSize must be 0, 256, 512 or 768");
   if (launchThreshold > 0) c->launchThreshold = launchThreshold;
   if (surfaceThreshold > 0) c->surfaceThreshold = surfaceThreshold;
   if (brickLayout >= 0 && brickLayout <= 2) { if (brickLayout != c->brickMode) c->tuned = false; c->brickMode = brickLayout; }
