@@ -190,3 +190,41 @@ def test_random_domains_against_face_by_face_walk(M, seed):
     assert np.all(np.abs(means[1] - means[0]) < 4e-3), (means[1], means[0])
     a = case["albedo"]
     assert abs(means[1][0] + means[1][2] + (1.0 - a) * means[1][1] - 1.0) < 4.0 / np.sqrt(n)
+
+
+@pytest.mark.parametrize("rr", [False, True])
+def test_radiance_rays_skip_layers_too(M, rr):
+    """Local estimates send a ray per view direction to the domain boundary; the rays take the clear layers above and
+    below a cloud field the way photons do.  Per-pixel radiances of one batch on the same Philox streams: against the
+    face-by-face kernel and against the oracle; views up and (without roulette) down, reflecting surface."""
+    from oracle import oracle as O
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.landsat_like(n=32, nz=24, n_entries=6, albedo=0.3)
+    mus, phis = ([1.0, 0.45, 0.2], [0.0, 100.0, 310.0]) if rr else ([1.0, 0.45, -0.6], [0.0, 100.0, 310.0])
+    n = 40000
+    got = {}
+    for skip in (0, 1):
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, minForwardTableSize=9001, intensityMus=mus, intensityPhis=phis,
+                                computeIntensity=True, useRussianRouletteForIntensity=rr, zetaMin=0.3)
+        integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=skip)
+        photons = M.new_PhotonStream(0.5, 30.0, numberOfPhotons=10 ** 9)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+        got[skip] = integ.reportResults()
+        integ.finalize()
+    P = cases.oracle_problem(case, nsteps=9001)
+    I = cases.oracle_intensity(case, mus, phis, n_angles=9001, use_russian_roulette=rr, zeta_min=0.3)
+    ref = O.compute_radiative_transfer_intensity(P, O.solar_source(0.5, 30.0), O.philox_rng(SEED, 0), n, I)
+    r = ref["intensity"].reshape(-1, 32, 32).transpose(2, 1, 0)
+    a, b = got[0]["intensity"], got[1]["intensity"]
+    assert a.shape == b.shape == r.shape == (32, 32, 3)
+    # ~40 photons per column: a photon whose history flips moves a few percent of a pixel, so compare the
+    # direction means tightly and the pixels against the noise level of the field itself
+    assert np.allclose(got[1]["meanIntensity"], got[0]["meanIntensity"], rtol=3e-3), (got[1]["meanIntensity"], got[0]["meanIntensity"])
+    assert np.allclose(got[1]["meanIntensity"], ref["meanIntensity"], rtol=4e-3), (got[1]["meanIntensity"], ref["meanIntensity"])
+    for d in range(3):
+        scale = float(np.mean(np.abs(r[:, :, d])))
+        assert np.mean(np.abs(b[:, :, d] - a[:, :, d])) < 0.02 * scale, (d, np.mean(np.abs(b[:, :, d] - a[:, :, d])) / scale)
+        assert np.mean(np.abs(b[:, :, d] - r[:, :, d])) < 0.03 * scale, (d, np.mean(np.abs(b[:, :, d] - r[:, :, d])) / scale)
