@@ -548,6 +548,7 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   }
   // small domains (grid, tables and tallies in LDS): LDS holds two workgroups per CU, and two workgroups of 12 waves
   // (6 per SIMD, 80 VGPRs) beat two of 8 (4 per SIMD, no spills) by 10 % on the step cloud (640 and 896 lanes lose)
+  // (radiance on LDS-resident domains keeps 512 lanes: 768 lanes at 80 VGPRs lose 20 % there)
   if (L.block == 768 && L.priv && L.gridLds && c->nDir == 0 && !debug)
     return L.tblLds ? launch_trace_t<768, true, 2, false, false>(c, p, L.lds, nBatches) : launch_trace_t<768, false, 2, false, false>(c, p, L.lds, nBatches);
   if (L.block >= 512) return debug ? launch_trace_b<512, true>(c, p, L, nBatches) : launch_trace_b<512, false>(c, p, L, nBatches);
