@@ -47,6 +47,9 @@ class Integrator:
         if not self._ctx:
             raise McbratError("new_Integrator: no usable HIP device %d (the MI355X library has no CPU fallback)" % device)
         self.device = int(device)
+        self._atmosphere = atmosphere
+        self.useSurfaceBDRF = False
+        self.surfaceBDRF = None
         self.minInverseTableSize = defaultMinInverseTableSize
         self.useRayTracing = True
         self.useRussianRoulette = True
@@ -85,6 +88,22 @@ class Integrator:
 
     def isReady_Integrator(self):
         return bool(self.readyToCompute)
+
+    def copy_Integrator(self):
+        """copy_Integrator (:1296-1376): a second integrator on the same domain with the same parameters.  The
+        reference also copies the last batch's results; here results live in the context that computed them."""
+        new = Integrator(self._atmosphere, self.device)
+        new.specifyParameters(minInverseTableSize=self.minInverseTableSize, useRayTracing=self.useRayTracing,
+                              useRussianRoulette=self.useRussianRoulette, LW_flag=self.LW_flag,
+                              intensityMus=self.intensityMus, intensityPhis=self.intensityPhis,
+                              computeIntensity=self.computeIntensity, minForwardTableSize=self.minForwardTableSize,
+                              useRussianRouletteForIntensity=self.useRussianRouletteForIntensity, zetaMin=self.zetaMin,
+                              useHybridPhaseFunsForIntenCalcs=self.useHybridPhaseFunsForIntenCalcs,
+                              hybridPhaseFunWidth=self.hybridPhaseFunWidth,
+                              numOrdersOrigPhaseFunIntenCalcs=self.numOrdersOrigPhaseFunIntenCalcs,
+                              limitIntensityContributions=self.limitIntensityContributions,
+                              maxIntensityContribution=self.maxIntensityContribution, surfaceBDRF=self.surfaceBDRF)
+        return new
 
     def _check(self, rc):
         check(self._ctx, rc)
@@ -150,6 +169,7 @@ class Integrator:
             refl = np.ascontiguousarray(surfaceBDRF.BRDFParameters[0].T, np.float32)  # x fastest
             self._check(self._lib.mcbrat_set_surface_description(self._ctx, int(x.size), int(y.size), ptr(x), ptr(y), ptr(refl)))
             self.useSurfaceBDRF = True
+            self.surfaceBDRF = surfaceBDRF
         for k, v in unsupported.items():
             if v not in (None, False):
                 raise McbratError("specifyParameters: keyword %s is not supported by the MI355X integrator" % k)

@@ -230,6 +230,18 @@ def test_surface_description_patches(M):
         mu, md, ma, _ = O.report_means(P, O.normalize(P, n, ref))
         for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
             assert abs(g - r) < 3e-3, (g, r)
+    # copy_Integrator (:1296-1376): same domain, same parameters (surface description included) -> same results
+    dom = cases.product_domain(case)
+    first = M.new_Integrator(dom)
+    first.specifyParameters(minInverseTableSize=9001, surfaceBDRF=cases.product_surface(case))
+    second = first.copy_Integrator()
+    out = []
+    for integ in (first, second):
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9), 5000)
+        out.append(integ.moments().copy())
+        integ.finalize()
+    assert np.array_equal(out[0], out[1])
     with pytest.raises(M.McbratError, match="surface description isn't valid"):
         integ2 = M.new_Integrator(cases.product_domain(cases.step_cloud(0.99)))
         integ2.specifyParameters(surfaceBDRF=object())
