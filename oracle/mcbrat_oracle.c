@@ -278,7 +278,7 @@ int orc_find_index_mixed(float vf, const double *t, int n, int firstGuess) { /* 
 /* makePeriodic, src/surfaceProperties.f95:211-230 (result kind is default real: the position is rounded to float) */
 static float make_periodic(double a, double aMin, double aMax) {
   float r = (float)a;
-  for (;;) {
+  for (int guard = 0; guard < 65536; ++guard) { /* (unbounded in the reference: endless where the period is below the float spacing of r) */
     if ((double)r <= aMax && (double)r > aMin) break;
     if ((double)r > aMax) r = (float)((double)r - (aMax - aMin));
     else if ((double)r == aMin) r = (float)aMax;
