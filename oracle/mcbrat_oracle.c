@@ -8,6 +8,15 @@
  * -ffast-math so that float/double expression order is what is written here.
  *
  * Who may use this: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline.
+ *
+ * Pinned (tests/test_oracle_pin.py): the findIndex family, Lobatto quadrature and Legendre
+ * polynomials bit for bit against the reference's own numericUtilities.f95 compiled here (oracle/_ref, fixtures in
+ * tests/golden/ref_numeric.json); MT19937 against its known answers and the reference stream recorded in SURVEY.md;
+ * the whole photon loop (solar source, regular grid, Legendre phase function, roulette) against the reference
+ * Fortran's own step-cloud outputs at 1e5 and 1e6 photons recorded in SURVEY.md section 8c / BASELINE.md, to all six
+ * printed digits.  Parity unpinned (restated from the source text only, no reference output recorded): thermal
+ * emission source and weighting, angle/value phase functions, irregular-grid launch, radiance by local estimation,
+ * the surface description.
  */
 #include "mcbrat_oracle.h"
 #include <float.h>
