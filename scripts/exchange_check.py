@@ -29,6 +29,7 @@ def run(case, mu0, phi0, ppb, nb, exchange, reps=1, tuning=None):
 
 
 which = sys.argv[1] if len(sys.argv) > 1 else "small"
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # 1: photon-exchange kernel, 2: served collisions
 if which == "small":
     todo = [("landsat48", cases.landsat_like(n=48, nz=24, n_entries=6), 0.5, 30.0, 20000, 3, None),
             ("landsat48 albedo", cases.landsat_like(n=48, nz=24, n_entries=6, albedo=0.4), 0.5, 30.0, 20000, 3, None),
@@ -47,5 +48,5 @@ else:
 for name, case, mu0, phi0, ppb, nb, tuning in todo:
     a, ra = run(case, mu0, phi0, ppb, nb, 0, reps, tuning)
     print("%-18s lane kernel     %.3g photons/s" % (name, ra), flush=True)
-    b, rb = run(case, mu0, phi0, ppb, nb, 1, reps, tuning)
-    print("%-18s exchange kernel %.3g photons/s   bitwise equal: %s  (max |diff| %.3g)" % (name, rb, np.array_equal(a, b), np.max(np.abs(a - b))), flush=True)
+    b, rb = run(case, mu0, phi0, ppb, nb, mode, reps, tuning)
+    print("%-18s mode %d kernel   %.3g photons/s   bitwise equal: %s  (max |diff| %.3g)" % (name, mode, rb, np.array_equal(a, b), np.max(np.abs(a - b))), flush=True)
