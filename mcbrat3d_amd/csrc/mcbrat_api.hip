@@ -534,49 +534,12 @@ int launch_trace_x(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatche
   return 0;
 }
 
-// Served collisions (trace_kernel_s, exchangeMode 2): the lane kernel's launch geometry plus a mailbox per lane.
-bool served_applies(const mcbrat_ctx *c, const LaunchPlan &L, bool debug) {
-  return c->exchangeMode == 2 && !debug && c->nDir == 0 && !L.brick && c->srcKind == 0 && !(c->lwFlag > 0.f);
-}
-
-template <int BLOCK, bool TBL, int PRIV>
-int launch_trace_s(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatches) {
-  int ring = 256;
-  while (ring < BLOCK) ring *= 2;
-  const size_t lds = ((L.lds + 15) & ~(size_t)15) + 32 + (size_t)ring * 4 + (size_t)BLOCK * 4 + (size_t)BLOCK * 48;
-  auto kernel = trace_kernel_s<BLOCK, TBL, PRIV>;
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int perCU = c->blocksPerCU;
-  if (perCU <= 0) {
-    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, BLOCK, lds));
-    perCU = std::max(1, std::min(perCU, 8));
-  }
-  unsigned long long blocks = (unsigned long long)perCU * c->numCUs;
-  if (PRIV) {
-    unsigned long long upb = std::max<unsigned long long>(1, blocks / (unsigned long long)nBatches);
-    upb = std::min<unsigned long long>(upb, std::max<unsigned long long>(1, p.ppb / (unsigned long long)(BLOCK * 8)));
-    p.unitsPerBatch = upb;
-    p.nUnits = upb * (unsigned long long)nBatches;
-    blocks = std::min(blocks, p.nUnits);
-  } else {
-    blocks = std::min(blocks, (p.total + BLOCK - 1) / BLOCK);
-  }
-  hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<unsigned long long>(1, blocks)), dim3(BLOCK), lds, c->L().stream, p, ring);
-  HIP_OK(c, hipGetLastError());
-  return 0;
-}
-
 int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   LaunchPlan L = plan_launch(c, (size_t)p.slabStride);
   if (L.priv && L.brick) {  // fill_params chose the brick arrays: private tallies give way
     L.priv = false;
     L.gridLds = false;
     L.lds = plan_launch_lds(c, L);
-  }
-  if (served_applies(c, L, debug)) {
-    if (L.priv && L.gridLds) return L.tblLds ? launch_trace_s<512, true, 2>(c, p, L, nBatches) : launch_trace_s<512, false, 2>(c, p, L, nBatches);
-    if (L.priv) return L.tblLds ? launch_trace_s<512, true, 1>(c, p, L, nBatches) : launch_trace_s<512, false, 1>(c, p, L, nBatches);
-    return L.tblLds ? launch_trace_s<256, true, 0>(c, p, L, nBatches) : launch_trace_s<256, false, 0>(c, p, L, nBatches);
   }
   if (exchange_applies(c, L, debug)) {
     if (L.priv && L.gridLds) return L.tblLds ? launch_trace_x<true, 2>(c, p, L, nBatches) : launch_trace_x<false, 2>(c, p, L, nBatches);
@@ -1069,7 +1032,7 @@ int mcbrat_set_surface_description(mcbrat_ctx *c, int32_t numX, int32_t numY, co
 int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip, int32_t exchange) {
   if (!c) return 1;
   if (layerSkip >= 0) { if ((layerSkip != 0) != (c->layerSkip != 0)) c->tuned = false; c->layerSkip = layerSkip ? 1 : 0; }
-  if (exchange >= 0 && exchange <= 2) { if (exchange != c->exchangeMode) c->tuned = false; c->exchangeMode = exchange; }
+  if (exchange >= 0) { if ((exchange != 0) != (c->exchangeMode != 0)) c->tuned = false; c->exchangeMode = exchange ? 1 : 0; }
   return 0;
 }
 

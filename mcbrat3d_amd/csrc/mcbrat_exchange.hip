@@ -611,532 +611,4 @@ __global__ void __launch_bounds__(BLOCK, MCBRAT_MIN_WAVES_PER_SIMD) trace_kernel
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// trace_kernel_s: the one-photon-per-lane kernel with SERVED collisions.  A photon stays in its lane (no slots, no
-// walk queue), but a lane whose leg ends in a collision posts a 48-byte record to its own LDS mailbox and queues its
-// thread number; whenever 64 records have queued up in the workgroup a wave processes them in one dense pass (optics,
-// absorption tally, roulette, scattering angle, new direction, the next leg's Philox block) and writes the results back
-// to the mailboxes, where the posting lanes pick them up on their next turn.  The collision code -- the bulk of an
-// event phase, which runs at 25-36 of 64 lanes in trace_kernel -- then runs with all lanes busy; launches, top exits,
-// surface reflections and the layer-skipping steps stay with the lane.  Same Philox slots and arithmetic: results are
-// bitwise those of trace_kernel.  Dense grids, directional source, fluxes only.
-// Mailbox of thread t: mail[3 t .. 3 t + 2] = {dx, dy, dz, w} {uX, uY, uZ, cell} {idLo, idHi, event, batch};
-// the answer overwrites {dx, dy, dz, w} {tau, uX, uY, uZ} and the event number.  s_flag[t]: 1 posted, 2 answered.
-constexpr int ST_POSTED = 7;
-
-template <int BLOCK, bool TBL_LDS, int PRIV>
-__global__ void __launch_bounds__(BLOCK, BLOCK > 512 ? BLOCK / 128 : (PRIV == 0 ? MCBRAT_WAVES_GLOBAL_GRID : MCBRAT_MIN_WAVES_PER_SIMD))
-trace_kernel_s(const DevParams p, const int ringCells) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  // LDS map: as trace_kernel, then [ring control (8 words)] [ring cells] [flags (BLOCK)] [mailboxes (BLOCK x 48 B)]
-  double *s_edge = reinterpret_cast<double *>(smem_raw);
-  const int nEdges = p.nx + p.ny + p.nz + 3;
-  const int ncol = p.nx * p.ny;
-  const int slabLen = PRIV ? (int)p.slabStride : 0;
-  long long *s_slab = reinterpret_cast<long long *>(s_edge + nEdges);
-  unsigned *s_cursor = reinterpret_cast<unsigned *>(s_slab + slabLen);
-  float *s_bgExt = reinterpret_cast<float *>(s_cursor + (PRIV ? 4 : 0));
-  constexpr bool gridLds = PRIV == 2;
-  const int nvoxS = gridLds ? ncol * p.nz : 0;
-  int *s_run = reinterpret_cast<int *>(s_bgExt + ((p.nz + 3) & ~3));
-  double *s_runT = reinterpret_cast<double *>(s_run + ((p.nz + 3) & ~3));
-  float *s_ext = reinterpret_cast<float *>(s_runT + ((p.nz + 2) & ~1));
-  float *s_ssa = s_ext + nvoxS;
-  float *s_cum = s_ssa + (size_t)p.nc * nvoxS;
-  uint16_t *s_pfi = reinterpret_cast<uint16_t *>(s_cum + (size_t)p.nc * nvoxS);
-  float *s_tbl = reinterpret_cast<float *>(s_pfi + (((size_t)p.nc * nvoxS + 1) & ~(size_t)1));
-  const size_t exOff = ((size_t)(reinterpret_cast<unsigned char *>(s_tbl + (TBL_LDS ? p.tblTotalFloats : 0)) - smem_raw) + 15) & ~(size_t)15;
-  unsigned *s_qctl = reinterpret_cast<unsigned *>(smem_raw + exOff);
-  unsigned *s_cells = s_qctl + 8;
-  unsigned *s_flag = s_cells + ringCells;
-  uint4 *s_mail = reinterpret_cast<uint4 *>(s_flag + BLOCK);
-  __shared__ int s_tblOffset[MCBRAT_MAX_COMPONENTS], s_tblNSteps[MCBRAT_MAX_COMPONENTS];
-  __shared__ float s_tblInvN[MCBRAT_MAX_COMPONENTS];
-  if (threadIdx.x < MCBRAT_MAX_COMPONENTS) {
-    s_tblOffset[threadIdx.x] = p.tblOffset[threadIdx.x];
-    s_tblNSteps[threadIdx.x] = p.tblNSteps[threadIdx.x];
-    s_tblInvN[threadIdx.x] = p.tblInvN[threadIdx.x];
-  }
-  for (int i = threadIdx.x; i < nEdges; i += BLOCK) s_edge[i] = p.edges[i];
-  if (TBL_LDS)
-    for (int i = threadIdx.x; i < p.tblTotalFloats; i += BLOCK) s_tbl[i] = p.tables[i];
-  if (PRIV) {
-    for (int i = threadIdx.x; i < slabLen; i += BLOCK) s_slab[i] = 0;
-    if (threadIdx.x == 0) s_cursor[0] = 0;
-  }
-  for (int i = threadIdx.x; i < p.nz; i += BLOCK) { s_bgExt[i] = p.bgExt[i]; s_run[i] = p.layerRun[i]; }
-  for (int i = threadIdx.x; i <= p.nz; i += BLOCK) s_runT[i] = p.layerRunT[i];
-  if (gridLds) {
-    for (int i = threadIdx.x; i < nvoxS; i += BLOCK) s_ext[i] = p.ext[i];
-    for (int i = threadIdx.x; i < p.nc * nvoxS; i += BLOCK) { s_ssa[i] = p.ssa[i]; s_cum[i] = p.cum[i]; s_pfi[i] = p.pfi[i]; }
-  }
-  for (int i = threadIdx.x; i < ringCells; i += BLOCK) s_cells[i] = (unsigned)i << 16;
-  if (threadIdx.x < 8) s_qctl[threadIdx.x] = 0u;
-  s_flag[threadIdx.x] = 0u;
-  __syncthreads();
-  const float *__restrict__ tbl = TBL_LDS ? s_tbl : p.tables;
-  const int offY = p.nx + 1, offZ = p.nx + p.ny + 2;
-  const float *extG = p.ext;
-  asm volatile("" : "+s"(extG));
-  const int lane = threadIdx.x & (kWave - 1);
-  const unsigned long long laneBelow = (1ull << lane) - 1ull;
-  const unsigned ringMask = (unsigned)ringCells - 1u;
-
-  unsigned long long unitFirst = 0;
-  unsigned unitCount = 0;
-  long long *unitSlab = nullptr;
-
-  int state = ST_DEAD;
-  bool more = true;
-  uint32_t idLo = 0, idHi = 0, event = 0, batch = 0;
-  double px = 0, py = 0, pz = 0;
-  float dx = 0, dy = 0, dz = 1, ivx = 0, ivy = 0, ivz = 0;
-  float tnx = 0, tny = 0, tnz = 0, tcur = 0, acc = 0, tau = 0, w = 0, extCur = 0, uX = 0, uY = 0, uZ = 0;
-  int ex = 0, ey = 0, ez = 0, cell = 0;
-  constexpr bool LAZY = PRIV != 2;
-  bool lazy = false;
-  unsigned long long chunkNext = 0, chunkEnd = 0;
-
-  auto tryJump = [&]() {  // (trace_kernel: same function)
-    const bool up = dz >= 0.0f;
-    const int k = ez - offZ - (up ? 1 : 0);
-    const int run = s_run[k];
-    const int fEnd = up ? (run >> 16) : (run & 0xffff);
-    const double dT = up ? s_runT[fEnd] - s_runT[k + 1] : s_runT[k] - s_runT[fEnd];
-    const float accEnd = acc + (tnz - tcur) * extCur + (float)dT * fabsf(ivz);
-    lazy = true;
-    tnx = FLT_MAX; tny = FLT_MAX;
-    state = ST_WALK;
-    if (accEnd <= tau) {
-      acc = accEnd;
-      tcur = (float)(s_edge[offZ + fEnd] - pz) * ivz;
-      if (up) { ez = offZ + fEnd + 1; state = fEnd == p.nz ? ST_TOP : ST_ENTER; }
-      else { ez = offZ + fEnd - 1; state = fEnd == 0 ? ST_SURFACE : ST_ENTER; }
-      if (state == ST_SURFACE) extCur = s_bgExt[0];
-      tnz = (float)(s_edge[min(max(ez, offZ), offZ + p.nz)] - pz) * ivz;
-    }
-  };
-  auto resolveXY = [&]() {  // (trace_kernel: same function)
-    const float tc = state == ST_COLLIDE ? tcur + div_fast(tau - acc, extCur) : tcur;
-    const double xw = px + (double)tc * (double)dx, yw = py + (double)tc * (double)dy;
-    const int jx = locate_periodic(s_edge, p.nx, p.x0, p.Lx, p.invLx, p.invCellX, p.xyNearUniform != 0, px, xw);
-    const int jy = locate_periodic(s_edge + offY, p.ny, p.y0, p.Ly, p.invLy, p.invCellY, p.xyNearUniform != 0, py, yw);
-    ex = jx + (dx >= 0.0f ? 1 : 0);
-    ey = offY + jy + (dy >= 0.0f ? 1 : 0);
-    tnx = ivx != 0.0f ? (float)(s_edge[ex] - px) * ivx : FLT_MAX;
-    tny = ivy != 0.0f ? (float)(s_edge[ey] - py) * ivy : FLT_MAX;
-    cell = jx + p.nx * (jy + p.ny * (ez - offZ - (dz >= 0.0f ? 1 : 0)));
-    lazy = false;
-    if (state == ST_ENTER) { extCur = p.ext[cell]; state = ST_WALK; }
-  };
-
-  for (unsigned long long unit = blockIdx.x;; unit += gridDim.x) {
-    if (PRIV) {
-      if (unit >= p.nUnits) break;
-      const unsigned long long b = unit / p.unitsPerBatch, s = unit % p.unitsPerBatch;
-      const unsigned long long bp = (p.total - b * p.ppb) < p.ppb ? (p.total - b * p.ppb) : p.ppb;
-      const unsigned long long lo = (bp * s) / p.unitsPerBatch, hi = (bp * (s + 1)) / p.unitsPerBatch;
-      unitFirst = b * p.ppb + lo;
-      unitCount = (unsigned)(hi - lo);
-      unitSlab = p.slabs + b * p.slabStride;
-      batch = (uint32_t)b;
-      more = true;
-    }
-
-    for (;;) {
-      bool worked = false;
-      // ================= the lane's own turn =============================================================
-      bool needLeg = false, newBlock = false;  // newBlock: the leg's Philox block is still to be drawn here
-      // answers to posted collisions
-      if (state == ST_POSTED && x_load(&s_flag[threadIdx.x]) == 2u) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint4 r0 = s_mail[3 * threadIdx.x], r1 = s_mail[3 * threadIdx.x + 1];
-        event = s_mail[3 * threadIdx.x + 2].z;
-        x_store(&s_flag[threadIdx.x], 0u);
-        w = __uint_as_float(r0.w);
-        if (w <= FLT_MIN) {
-          state = ST_DEAD;
-        } else {
-          dx = __uint_as_float(r0.x); dy = __uint_as_float(r0.y); dz = __uint_as_float(r0.z);
-          tau = __uint_as_float(r1.x); uX = __uint_as_float(r1.y); uY = __uint_as_float(r1.z); uZ = __uint_as_float(r1.w);
-          needLeg = true;
-          state = ST_COLLIDE;  // (the leg starts in the cell of the collision; set to ST_WALK below)
-        }
-      }
-      if (LAZY) {
-        if (state == ST_JUMP) tryJump();
-        if (lazy && state != ST_WALK && state != ST_DEAD && state != ST_POSTED && !needLeg) resolveXY();
-      }
-      int ix = ex - (dx >= 0.0f ? 1 : 0), iy = ey - offY - (dy >= 0.0f ? 1 : 0), iz = ez - offZ - (dz >= 0.0f ? 1 : 0);
-      if (needLeg) { ix = ex; iy = ey - offY; iz = ez - offZ; }  // (a posted lane keeps its cell indices in ex, ey, ez)
-      const unsigned long long mDead = __ballot(state == ST_DEAD && more);
-      const unsigned long long mSurf = __ballot(state == ST_SURFACE);
-      const int nBusy = __popcll(__ballot(state == ST_WALK || state == ST_COLLIDE || state == ST_TOP || state == ST_POSTED));
-      const bool doLaunch = __popcll(mDead) >= p.launchThreshold || nBusy < p.eventThreshold;
-      const bool doSurface = __popcll(mSurf) >= p.surfaceThreshold || nBusy < p.eventThreshold;
-      const unsigned long long want = doLaunch ? mDead : 0ull;
-      if (want != 0ull) {  // wave-uniform: launches, as in trace_kernel
-        worked = true;
-        const int nWant = __popcll(want);
-        const int rank = __popcll(want & laneBelow);
-        unsigned long long myIdx;
-        bool valid;
-        if (PRIV) {
-          unsigned base = 0;
-          if (lane == 0) base = atomicAdd(&s_cursor[0], (unsigned)nWant);
-          base = (unsigned)__shfl((int)base, 0);
-          const unsigned k = base + (unsigned)rank;
-          valid = k < unitCount;
-          myIdx = unitFirst + k;
-        } else {
-          myIdx = chunkNext + (unsigned long long)rank;
-          const unsigned long long avail = chunkEnd - chunkNext;
-          if (avail < (unsigned long long)nWant) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(p.counter, (unsigned long long)kChunk);
-            const uint32_t bl = __shfl((int)(uint32_t)base, 0), bh = __shfl((int)(uint32_t)(base >> 32), 0);
-            base = ((unsigned long long)bh << 32) | bl;
-            if ((unsigned long long)rank >= avail) myIdx = base + ((unsigned long long)rank - avail);
-            chunkNext = base + ((unsigned long long)nWant - avail);
-            chunkEnd = base + kChunk;
-          } else {
-            chunkNext += (unsigned long long)nWant;
-          }
-          valid = myIdx < p.total;
-        }
-        if (state == ST_DEAD && more) {
-          if (valid) {
-            if (!PRIV) batch = (uint32_t)(myIdx / p.ppb);
-            const unsigned long long id = p.firstPhoton + myIdx;
-            idLo = (uint32_t)id; idHi = (uint32_t)(id >> 32);
-            event = 0;
-            uint32_t r[4];
-            philox4x32_10(0u, 0u, idLo, idHi, p.seedLo, p.seedHi, r);
-            const double fx = (double)u01(r[0]), fy = (double)u01(r[1]);
-            dx = p.dir0[0]; dy = p.dir0[1]; dz = p.dir0[2];
-            w = 1.0f;
-            px = p.x0 + fx * (p.xMax - p.x0);
-            py = p.y0 + fy * (p.yMax - p.y0);
-            if (p.xyRegular) {
-              ix = min((int)((px - p.x0) * p.invDX), p.nx - 1);
-              iy = min((int)((py - p.y0) * p.invDY), p.ny - 1);
-            } else {
-              ix = find_cell(s_edge, p.nx, px);
-              iy = find_cell(s_edge + offY, p.ny, py);
-            }
-            pz = p.zLaunch; iz = p.izLaunch;
-            cell = ix + p.nx * (iy + p.ny * iz);
-            extCur = gridLds ? s_ext[cell] : p.ext[cell];
-            needLeg = true; newBlock = true;
-          } else {
-            more = false;
-          }
-        }
-      }
-      if (state == ST_TOP) {  // out the top, computeRT :573-617
-        const unsigned long long dep = weight_to_fixed(w);
-        if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + (ix + p.nx * iy)), dep);
-        else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + (ix + p.nx * iy)), dep);
-        state = ST_DEAD;
-        worked = true;
-      }
-      // collisions: the point where tau is used up (opticalProperties.f95:1729-1738), then the record goes to the queue
-      const bool post = state == ST_COLLIDE && !needLeg;
-      if (post) {
-        const double s = (double)(tcur + div_fast(tau - acc, extCur));
-        px = px + s * (double)dx;
-        py = py + s * (double)dy;
-        pz = pz + s * (double)dz;
-        s_mail[3 * threadIdx.x] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), __float_as_uint(w));
-        s_mail[3 * threadIdx.x + 1] = make_uint4(__float_as_uint(uX), __float_as_uint(uY), __float_as_uint(uZ), (unsigned)cell);
-        s_mail[3 * threadIdx.x + 2] = make_uint4(idLo, idHi, event, batch);
-        x_store(&s_flag[threadIdx.x], 1u);
-        ex = ix; ey = offY + iy; ez = offZ + iz;  // the direction is about to change: keep the cell, not the faces ahead
-        state = ST_POSTED;
-      }
-      {
-        const unsigned long long m = __ballot(post);
-        if (m != 0ull) {  // (xq_push with the ring size of this kernel)
-          worked = true;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          const int leader = __ffsll((long long)m) - 1;
-          unsigned base = 0;
-          if (lane == leader) base = atomicAdd(&s_qctl[1], (unsigned)__popcll(m));
-          base = (unsigned)__shfl((int)base, leader);
-          if (post) {
-            const unsigned pos = base + (unsigned)__popcll(m & laneBelow);
-            unsigned *cellp = s_cells + (pos & ringMask);
-            while ((x_load(cellp) >> 16) != (pos & 0xffffu)) __builtin_amdgcn_s_sleep(1);
-            x_store(cellp, (((pos + 1u) & 0xffffu) << 16) | threadIdx.x);
-          }
-        }
-      }
-      if (state == ST_SURFACE && doSurface) {  // surface, computeRT :619-676 (trace_kernel: same code)
-        worked = true;
-        px = px + (double)tcur * (double)dx;
-        py = py + (double)tcur * (double)dy;
-        pz = p.zSurf;
-        iz = 0;
-        cell = ix + p.nx * iy;
-        const unsigned long long dep = weight_to_fixed(w);
-        if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + ncol + (ix + p.nx * iy)), dep);
-        else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)batch * p.slabStride + ncol + (ix + p.nx * iy)), dep);
-        float mu = sqrtf(uX);
-        if (!(fabsf(mu) > 2.0f * FLT_MIN)) {
-          mu = sqrtf(uZ);
-          uint32_t r[4];
-          for (uint32_t j = 0; !(fabsf(mu) > 2.0f * FLT_MIN); j++) {
-            if ((j & 3u) == 0) philox4x32_10(event, 2u + (j >> 2), idLo, idHi, p.seedLo, p.seedHi, r);
-            mu = sqrtf(u01(pick4(r, j & 3u)));
-          }
-        }
-        if (p.surfNumX > 0) w = w * surface_reflectance(p, px, py);
-        else w = (float)((double)w * (double)p.albedo);
-        if (w <= FLT_MIN) {
-          state = ST_DEAD;
-        } else {
-          const float sinTheta = sqrtf(1.0f - mu * mu);
-          float cphi, sphi;
-          sincos_2pi(uY, cphi, sphi);
-          dx = sinTheta * cphi; dy = sinTheta * sphi; dz = mu;
-          needLeg = true; newBlock = true;
-        }
-      }
-      if (needLeg) {  // start the next leg (trace_kernel: same code; an answered collision brings its block along)
-        worked = true;
-        if (newBlock) {
-          event++;
-          uint32_t r[4];
-          philox4x32_10(event, 0u, idLo, idHi, p.seedLo, p.seedHi, r);
-#ifdef MCBRAT_PRECISE_MATH
-          tau = -logf(fmaxf(FLT_MIN, u01(r[0])));
-#else
-          tau = -0.693147182f * __builtin_amdgcn_logf(fmaxf(FLT_MIN, u01(r[0])));
-#endif
-          uX = u01(r[1]); uY = u01(r[2]); uZ = u01(r[3]);
-        }
-        acc = 0.0f; tcur = 0.0f;
-        ex = ix + (dx >= 0.0f ? 1 : 0);
-        ey = offY + iy + (dy >= 0.0f ? 1 : 0);
-        ez = offZ + iz + (dz >= 0.0f ? 1 : 0);
-        if (fabsf(dz) >= 2.0f * FLT_MIN) { ivz = rcp_fast(dz); tnz = (float)(s_edge[ez] - pz) * ivz; }
-        else { ivz = 0.0f; tnz = FLT_MAX; }
-        ivx = fabsf(dx) >= 2.0f * FLT_MIN ? rcp_fast(dx) : 0.0f;
-        ivy = fabsf(dy) >= 2.0f * FLT_MIN ? rcp_fast(dy) : 0.0f;
-        state = ST_WALK;
-        lazy = false;
-        if (LAZY && p.layerSkip && ivz != 0.0f && s_bgExt[iz] >= 0.0f) {
-          tryJump();
-          if (state == ST_ENTER) resolveXY();
-        } else {
-          tnx = ivx != 0.0f ? (float)(s_edge[ex] - px) * ivx : FLT_MAX;
-          tny = ivy != 0.0f ? (float)(s_edge[ey] - py) * ivy : FLT_MAX;
-        }
-      }
-      if (__ballot(state != ST_DEAD || more) == 0ull) break;
-
-      // ================= a dense pass over queued collisions =============================================
-      const int nWalkers = __popcll(__ballot(state == ST_WALK));
-      const int cnt = xq_count(s_qctl);
-      if (cnt >= kWave || (cnt > 0 && nWalkers == 0)) {
-        int es = -1;
-        {  // (xq_pop with the ring size of this kernel)
-          unsigned base = 0, n = 0;
-          if (lane == 0) {
-            const unsigned need = nWalkers == 0 ? 1u : (unsigned)kWave;
-            unsigned h = x_load(&s_qctl[0]);
-            for (;;) {
-              const int avail = (int)(x_load(&s_qctl[1]) - h);
-              n = avail < kWave ? (unsigned)(avail > 0 ? avail : 0) : (unsigned)kWave;
-              if (n == 0 || n < need) { n = 0; break; }
-              const unsigned old = atomicCAS(&s_qctl[0], h, h + n);
-              if (old == h) { base = h; break; }
-              h = old;
-            }
-          }
-          base = (unsigned)__shfl((int)base, 0);
-          n = (unsigned)__shfl((int)n, 0);
-          if ((unsigned)lane < n) {
-            const unsigned pos = base + (unsigned)lane;
-            unsigned *cellp = s_cells + (pos & ringMask);
-            unsigned cv;
-            while (((cv = x_load(cellp)) >> 16) != ((pos + 1u) & 0xffffu)) __builtin_amdgcn_s_sleep(1);
-            es = (int)(cv & 0xffffu);
-            x_store(cellp, ((pos + (unsigned)ringCells) & 0xffffu) << 16);
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        if (__ballot(es >= 0) != 0ull) {
-          worked = true;
-          if (es >= 0) {
-            const uint4 m0 = s_mail[3 * es], m1 = s_mail[3 * es + 1], m2 = s_mail[3 * es + 2];
-            float edx = __uint_as_float(m0.x), edy = __uint_as_float(m0.y), edz = __uint_as_float(m0.z), ew = __uint_as_float(m0.w);
-            const float eX = __uint_as_float(m1.x), eY = __uint_as_float(m1.y), eZ = __uint_as_float(m1.z);
-            const int ecell = (int)m1.w;
-            const uint32_t eLo = m2.x, eHi = m2.y, ebatch = m2.w;
-            uint32_t eevent = m2.z;
-            // scattering event, computeRT :703-821 (trace_kernel: same arithmetic)
-            const long long nvox = (long long)ncol * p.nz;
-            int c = 0;
-            float ssa;
-            int pfEntry;
-            if (!gridLds && p.rec) {
-              const uint4 rc = p.rec[ecell];
-              c = eZ >= __uint_as_float(rc.x) ? 1 : 0;
-              ssa = __uint_as_float(c ? rc.z : rc.y);
-              pfEntry = (int)(c ? (rc.w >> 16) : (rc.w & 0xffffu));
-            } else {
-              const float *cumA = gridLds ? s_cum : p.cum;
-              const float *ssaA = gridLds ? s_ssa : p.ssa;
-              const uint16_t *pfiA = gridLds ? s_pfi : p.pfi;
-              if (p.nc > 1) {
-                for (int k = 0; k < p.nc - 1; k++)
-                  if (eZ >= cumA[(long long)k * nvox + ecell]) c = k + 1;
-              }
-              ssa = ssaA[(long long)c * nvox + ecell];
-              pfEntry = pfiA[(long long)c * nvox + ecell];
-            }
-            if (ssa < 1.0f) {  // absorption :765-771
-              const unsigned long long dep = weight_to_fixed(ew * (1.0f - ssa));
-              if (PRIV) atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + ecell), dep);
-              else atomicAdd(reinterpret_cast<unsigned long long *>(p.slabs + (unsigned long long)ebatch * p.slabStride + 2 * ncol + ecell), dep);
-              ew = ew * ssa;
-            }
-            if (p.useRR && ew < 0.5f) {  // Russian roulette :805-811
-              uint32_t r1[4];
-              philox4x32_10(eevent, 1u, eLo, eHi, p.seedLo, p.seedHi, r1);
-              ew = u01(r1[1]) >= ew ? 0.0f : 1.0f;
-            }
-            uint4 a1 = make_uint4(0u, 0u, 0u, 0u);
-            if (ew > FLT_MIN) {
-              const int n = s_tblNSteps[c];
-              const float *t = tbl + s_tblOffset[c] + (long long)pfEntry * n;
-              const int ai = (int)(eX * (float)n) + 1;
-              float ang;
-              if (ai < n) {
-#ifdef MCBRAT_PRECISE_MATH
-                const float left = eX - (float)(ai - 1) / (float)n;
-#else
-                const float left = eX - (float)(ai - 1) * s_tblInvN[c];
-#endif
-                ang = (1.0f - left) * t[ai - 1] + left * t[ai];
-              } else {
-                ang = t[n - 1];
-              }
-#ifdef MCBRAT_PRECISE_MATH
-              const float cs = cosf(ang);
-#else
-              const float cs = cos_0_pi(ang);
-#endif
-              float AX, AY;
-              sincos_2pi(eY, AX, AY);
-#ifdef MCBRAT_PRECISE_MATH
-              float B = sqrtf(1.0f - cs * cs);
-#else
-              float B = __builtin_amdgcn_sqrtf(1.0f - cs * cs);
-#endif
-              AX = AX * B;
-              AY = AY * B;
-              B = edx * AX - edy * AY;
-              const float D = cs - div_fast(B, 1.0f + fabsf(edz));
-              const float ndx = edx * D + AX, ndy = edy * D - AY;
-              edz = edz * cs - copysignf(fabsf(B), edz * B);
-              edx = ndx; edy = ndy;
-              eevent++;
-              uint32_t r[4];
-              philox4x32_10(eevent, 0u, eLo, eHi, p.seedLo, p.seedHi, r);
-#ifdef MCBRAT_PRECISE_MATH
-              const float ntau = -logf(fmaxf(FLT_MIN, u01(r[0])));
-#else
-              const float ntau = -0.693147182f * __builtin_amdgcn_logf(fmaxf(FLT_MIN, u01(r[0])));
-#endif
-              a1 = make_uint4(__float_as_uint(ntau), __float_as_uint(u01(r[1])), __float_as_uint(u01(r[2])), __float_as_uint(u01(r[3])));
-            }
-            s_mail[3 * es] = make_uint4(__float_as_uint(edx), __float_as_uint(edy), __float_as_uint(edz), __float_as_uint(ew));
-            s_mail[3 * es + 1] = a1;
-            reinterpret_cast<unsigned *>(s_mail + 3 * es + 2)[2] = eevent;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            x_store(&s_flag[es], 2u);
-          }
-        }
-      }
-
-      // ================= walk: one voxel face per iteration (trace_kernel's loop) =========================
-      if (nWalkers > 0) {
-        worked = true;
-        int nWalk;
-        unsigned sinceTurn = 0;
-        do {
-          if (state == ST_WALK) {
-            const bool yLtX = tny < tnx;
-            const float m2 = yLtX ? tny : tnx;
-            const bool isZ = tnz < m2;
-            const float tmin = isZ ? tnz : m2;
-            const float accNew = acc + (tmin - tcur) * extCur;
-            if (accNew > tau) {
-              state = ST_COLLIDE;
-            } else {
-              acc = accNew;
-              tcur = tmin;
-              if (isZ) {
-                ez += dz >= 0.0f ? 1 : -1;
-                if (ez > offZ + p.nz) state = ST_TOP;
-                else if (ez < offZ) state = ST_SURFACE;
-                else cell += dz >= 0.0f ? ncol : -ncol;
-              } else if (yLtX) {
-                ey += dy >= 0.0f ? 1 : -1;
-                cell += dy >= 0.0f ? p.nx : -p.nx;
-                if (ey > offY + p.ny) { ey = offY + 1; cell -= ncol; py -= p.Ly; }
-                else if (ey < offY) { ey = offY + p.ny - 1; cell += ncol; py += p.Ly; }
-              } else {
-                ex += dx >= 0.0f ? 1 : -1;
-                cell += dx >= 0.0f ? 1 : -1;
-                if (ex > p.nx) { ex = 1; cell -= p.nx; px -= p.Lx; }
-                else if (ex < 0) { ex = p.nx - 1; cell += p.nx; px += p.Lx; }
-              }
-              if (gridLds) extCur = s_ext[cell];
-              else if (state == ST_WALK) {
-                const int k = ez - offZ - (dz >= 0.0f ? 1 : 0);
-                const float lv = s_bgExt[k];
-                if (LAZY && p.layerSkip && isZ && (lv >= 0.0f) != lazy) state = lazy ? ST_ENTER : ST_JUMP;
-                extCur = lv;
-                if (lv < 0.0f && state == ST_WALK) extCur = extG[cell];
-              }
-              const bool spaced = isZ ? p.zRegularWalk != 0 : p.xyRegularWalk != 0;
-              float tNew = tmin + (isZ ? p.dZf * fabsf(ivz) : (yLtX ? p.dYf * fabsf(ivy) : p.dXf * fabsf(ivx)));
-              if (!spaced) {
-                const int eSel = isZ ? min(max(ez, offZ), offZ + p.nz) : (yLtX ? ey : ex);
-                const double edge = s_edge[eSel];
-                const double origin = isZ ? pz : (yLtX ? py : px);
-                const float iv = isZ ? ivz : (yLtX ? ivy : ivx);
-                tNew = (float)(edge - origin) * iv;
-              }
-              tnz = isZ ? tNew : tnz;
-              tny = (!isZ && yLtX) ? tNew : tny;
-              tnx = (!isZ && !yLtX) ? tNew : tnx;
-            }
-          }
-          nWalk = __popcll(__ballot(state == ST_WALK));
-          // below the threshold the wave takes its turn when a lane has stopped since the last one -- or every
-          // eighth iteration, to look for answers to the collisions it has posted
-          if (nWalk < p.eventThreshold && (__ballot(state != ST_WALK && state != ST_DEAD && state != ST_POSTED) != 0ull || (++sinceTurn & 7) == 0)) break;
-        } while (nWalk > 0);
-      }
-      if (!worked) __builtin_amdgcn_s_sleep(4);
-    }
-
-    if (!PRIV) break;
-    __syncthreads();
-    for (int i = threadIdx.x; i < slabLen; i += BLOCK) {
-      const long long v = s_slab[i];
-      if (v != 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(unitSlab + i), (unsigned long long)v);
-        s_slab[i] = 0;
-      }
-    }
-    if (threadIdx.x == 0) s_cursor[0] = 0;
-    __syncthreads();
-  }
-}
-
 }  // namespace mcbrat

@@ -29,7 +29,7 @@ def run(case, mu0, phi0, ppb, nb, exchange, reps=1, tuning=None):
 
 
 which = sys.argv[1] if len(sys.argv) > 1 else "small"
-mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # 1: photon-exchange kernel, 2: served collisions
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # 1: photon-exchange kernel
 if which == "small":
     todo = [("landsat48", cases.landsat_like(n=48, nz=24, n_entries=6), 0.5, 30.0, 20000, 3, None),
             ("landsat48 albedo", cases.landsat_like(n=48, nz=24, n_entries=6, albedo=0.4), 0.5, 30.0, 20000, 3, None),
