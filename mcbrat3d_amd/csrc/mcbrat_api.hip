@@ -451,6 +451,10 @@ size_t plan_launch_lds(const mcbrat_ctx *c, const LaunchPlan &L) {
 
 template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN = false>
 int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
+  if (lds > c->ldsPerCU) return fail(c, "computeRadiativeTransfer: the grid's edge and layer tables do not fit the LDS of a compute unit.");
+  if (lds > kLdsBudget)  // (very tall grids: the per-layer tables alone can pass the default limit of a workgroup)
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int perCU = c->blocksPerCU;
   if (perCU <= 0) {
     HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN>, BLOCK, lds));

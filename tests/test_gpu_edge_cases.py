@@ -245,3 +245,22 @@ def test_surface_description_patches(M):
     with pytest.raises(M.McbratError, match="surface description isn't valid"):
         integ2 = M.new_Integrator(cases.product_domain(cases.step_cloud(0.99)))
         integ2.specifyParameters(surfaceBDRF=object())
+
+
+def test_very_tall_grid(M):
+    """3000 layers on 2 x 2 columns: the edge and per-layer tables (72 KB) pass the default LDS limit of a workgroup."""
+    nz = 3000
+    ze = np.linspace(0.0, 3.0, nz + 1)
+    ext = np.full((2, 2, nz), 1.5)
+    ext[:, :, 1000:2000] = 0.0          # a run of 1000 clear layers in the middle
+    ext[0, 0, ::7] = 3.0                # and layers with cell-to-cell extinction below and above it
+    ext[0, 0, 1000:2000] = 0.0
+    case = dict(name="tall", xe=np.array([0.0, 0.1, 0.2]), ye=np.array([0.0, 0.1, 0.2]), ze=ze, albedo=0.2,
+                components=[dict(ext=ext, ssa=np.where(ext > 0, 0.9, 0.0), pfIndex=np.ones(ext.shape, np.int32),
+                                 legendre=[cases.hg_legendre(0.7, 16)])])
+    n = 20000
+    done, st, last, _ = _run(M, case, 0.8, 40.0, n, 1)
+    ref = _oracle(case, 0.8, 40.0, n)
+    assert done == n
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert abs(last[k] - ref[k]) < 3e-3, (k, last[k], ref[k])
