@@ -39,6 +39,9 @@ WORKLOADS = {
                           cpu=8000000, parity=400000000),
     "landsatLike128": dict(make=lambda: cases.landsat_like(), mu0=0.5, phi0=30.0, ppb=1000000, batches=100,
                            cpu=2000000, parity=100000000),
+    # config 5: optically thick, omega0 = 0.9, roulette-heavy; not a headline line, kept for its parity record
+    "radarLike128": dict(make=lambda: cases.radar_like(), mu0=0.5, phi0=30.0, ppb=1000000, batches=100,
+                         cpu=4000000, parity=100000000),
 }
 
 
