@@ -115,6 +115,8 @@ struct mcbrat_ctx {
   int gridLdsMode = 1;         // stage the optical grid in LDS when it fits (private-tally mode)
   int exchangeMode = 0;        // photon-exchange form of the tracing kernel where it applies: opt-in (MCBRAT_EXCHANGE=1 / mcbrat_set_walk_options), see DESIGN.md
   int flushLanes = 16;         // exchange kernel: lanes of a wave that have stopped before it hands legs over (MCBRAT_FLUSH_LANES)
+  int rayShort = 0, rayPassIters = 0, rayPassAt = 0;  // 0: chosen in launch_trace_b (MCBRAT_RAY_SHORT, MCBRAT_RAY_PASS_ITERS, MCBRAT_RAY_PASS_AT)
+  int rayDefer = 1;            // radiance: long rays are put aside and finished in dense passes (MCBRAT_RAY_DEFER=0: inside their event phase)
   int layerSkip = 1;           // layers of one extinction value: cross z faces only (MCBRAT_LAYER_SKIP=0 / mcbrat_set_walk_options)
   bool countersOn = false;
   float lastTraceMs = 0.f;
@@ -483,12 +485,25 @@ int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatche
   // radiance runs: dense grids, no instrumentation
   if (c->nDir > 0) {
     if (DBG) return fail(c, "computeRadiativeTransfer: event counters / photon fates are not available together with intensity directions.");
-    if (L.priv && L.gridLds) return L.tblLds ? launch_trace_t<BLOCK, true, 2, false, false, true>(c, p, L.lds, nBatches)
-                                             : launch_trace_t<BLOCK, false, 2, false, false, true>(c, p, L.lds, nBatches);
-    if (L.priv) return L.tblLds ? launch_trace_t<BLOCK, true, 1, false, false, true>(c, p, L.lds, nBatches)
-                                : launch_trace_t<BLOCK, false, 1, false, false, true>(c, p, L.lds, nBatches);
-    return L.tblLds ? launch_trace_t<BLOCK, true, 0, false, false, true>(c, p, L.lds, nBatches)
-                    : launch_trace_t<BLOCK, false, 0, false, false, true>(c, p, L.lds, nBatches);
+    // the waves' buffers of unfinished long rays (80 B per ray) take what LDS is left at the residency the kernel is built
+    // for: 5 workgroups of 256 lanes per CU on grids in global memory, 2 workgroups otherwise
+    const size_t waves = BLOCK / 64, base = (L.lds + 15) & ~(size_t)15;
+    const size_t budget = c->ldsPerCU / (L.priv ? 2 : (BLOCK == 256 ? 5 : 2));
+    size_t cap = (c->rayDefer && budget > base + 64) ? std::min<size_t>(64, (budget - base - 64) / (waves * 80)) : 0;
+    if (cap < 24) cap = 0;
+    p.rayCap = (int)cap;
+    // measured on the 128x128x64 cloud field, 4 directions: with roulette most rays end within a few cells and the long
+    // ones are best served in short, dense passes; without it every ray runs to the boundary and long passes pay
+    p.rayShort = c->rayShort > 0 ? c->rayShort : (c->useRRIntensity ? 4 : 8);
+    p.rayPassIters = c->rayPassIters > 0 ? c->rayPassIters : (c->useRRIntensity ? 16 : 64);
+    p.rayPassAt = std::min<int>(c->rayPassAt > 0 ? c->rayPassAt : (c->useRRIntensity ? 56 : 40), (int)cap);
+    const size_t lds = base + waves * cap * 80;
+    if (L.priv && L.gridLds) return L.tblLds ? launch_trace_t<BLOCK, true, 2, false, false, true>(c, p, lds, nBatches)
+                                             : launch_trace_t<BLOCK, false, 2, false, false, true>(c, p, lds, nBatches);
+    if (L.priv) return L.tblLds ? launch_trace_t<BLOCK, true, 1, false, false, true>(c, p, lds, nBatches)
+                                : launch_trace_t<BLOCK, false, 1, false, false, true>(c, p, lds, nBatches);
+    return L.tblLds ? launch_trace_t<BLOCK, true, 0, false, false, true>(c, p, lds, nBatches)
+                    : launch_trace_t<BLOCK, false, 0, false, false, true>(c, p, lds, nBatches);
   }
   // instantiated combinations: private tallies (small domains) and bricks (large ones) never coincide
   if (L.priv && L.gridLds) return L.tblLds ? launch_trace_t<BLOCK, true, 2, false, DBG>(c, p, L.lds, nBatches)
@@ -620,6 +635,10 @@ mcbrat_ctx *mcbrat_create(int device) {
   c->device = device;
   if (const char *e = getenv("MCBRAT_REGULAR_WALK")) c->regularWalk = atoi(e);
   if (const char *e = getenv("MCBRAT_LAYER_SKIP")) c->layerSkip = atoi(e);
+  if (const char *e = getenv("MCBRAT_RAY_DEFER")) c->rayDefer = atoi(e);
+  if (const char *e = getenv("MCBRAT_RAY_SHORT")) c->rayShort = std::max(1, atoi(e));
+  if (const char *e = getenv("MCBRAT_RAY_PASS_ITERS")) c->rayPassIters = std::max(1, atoi(e));
+  if (const char *e = getenv("MCBRAT_RAY_PASS_AT")) c->rayPassAt = std::max(1, atoi(e));
   if (const char *e = getenv("MCBRAT_EXCHANGE")) c->exchangeMode = atoi(e);
   if (const char *e = getenv("MCBRAT_FLUSH_LANES")) c->flushLanes = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_TUNE_PHOTONS")) c->tuneTrialPhotons = strtoull(e, nullptr, 10);

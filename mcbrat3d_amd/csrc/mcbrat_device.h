@@ -80,6 +80,8 @@ struct DevParams {
   int useHybrid, numOrdersOrig;   // original tables up to this scattering order, hybrid ones beyond
   int useRRIntensity;             // Iwabuchi (2006) roulette on the local estimates
   float zetaMin;
+  int rayShort, rayPassIters, rayPassAt;  // iterations a ray gets inside its event phase / in one pass over the buffer; rays in the buffer that start a pass
+  int rayCap;                     // unfinished long rays a wave can put aside in LDS (0: every ray is finished inside its event phase)
   int limitContrib;               // limitIntensityContributions: clip each local estimate, redistribute the excess (:294-320, :1815-1826)
   float maxContrib;
   // work

@@ -203,3 +203,29 @@ def test_intensity_error_paths(M):
     assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(1), photons, 1000) == 1000
     assert "intensity" not in integ.reportResults()
     integ.finalize()
+
+
+@pytest.mark.parametrize("rr", [False, True])
+def test_long_rays_put_aside_are_bitwise_the_rays_finished_in_place(M, rr, monkeypatch):
+    """After a few iterations what is left of a ray goes to the wave's LDS ray buffer and is finished later in a
+    dense pass with other long rays.  Same arithmetic per ray, integer tallies: the moment
+    arrays must be bitwise those of the kernel that finishes every ray inside its event phase (MCBRAT_RAY_DEFER=0).
+    Cloud field with clear air above and below, reflecting surface, three directions (one slanted at mu = 0.2)."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.landsat_like(n=32, nz=24, n_entries=6, albedo=0.3)
+    mus, phis = [1.0, 0.45, 0.2], [0.0, 100.0, 310.0]
+    out = {}
+    for defer in ("0", "1"):
+        monkeypatch.setenv("MCBRAT_RAY_DEFER", defer)  # read when the context is created
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, intensityMus=mus, intensityPhis=phis, computeIntensity=True,
+                                useRussianRouletteForIntensity=rr, limitIntensityContributions=True, maxIntensityContribution=0.5)
+        integ.setTuning(eventThreshold=24)
+        photons = M.new_PhotonStream(0.5, 30.0, numberOfPhotons=10 ** 9)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, 30000, 3)
+        out[defer] = integ.moments().copy()
+        integ.finalize()
+    assert np.array_equal(out["0"], out["1"])
+    assert out["1"][0] == 90000
