@@ -490,7 +490,7 @@ int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatche
     const size_t waves = BLOCK / 64, base = (L.lds + 15) & ~(size_t)15;
     const size_t budget = c->ldsPerCU / (L.priv ? 2 : (BLOCK == 256 ? 5 : 2));
     size_t cap = (c->rayDefer && budget > base + 64) ? std::min<size_t>(64, (budget - base - 64) / (waves * 80)) : 0;
-    if (cap < 24) cap = 0;
+    if (cap < 24 || c->nx + c->ny + c->nz + 3 > 0xffff || c->nDir > 0xffff) cap = 0;  // (a ray record packs edge-table indices and the direction in 16 bits)
     p.rayCap = (int)cap;
     // measured on the 128x128x64 cloud field, 4 directions: with roulette most rays end within a few cells and the long
     // ones are best served in short, dense passes; without it every ray runs to the boundary and long passes pay
