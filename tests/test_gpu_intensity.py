@@ -229,3 +229,29 @@ def test_long_rays_put_aside_are_bitwise_the_rays_finished_in_place(M, rr, monke
         integ.finalize()
     assert np.array_equal(out["0"], out["1"])
     assert out["1"][0] == 90000
+
+
+def test_radiance_is_independent_of_the_tally_mode(M):
+    """Grid and tallies in LDS, tallies only in LDS (grid in global memory: rays skip layers and long rays are put
+    aside there), everything in global memory: the same photons give bitwise the same moments."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.step_cloud(0.99)
+    case["components"][0]["ext"][:, :, 24:] = 0.0   # clear layers above the cloud: a run for photons and rays
+    case["albedo"] = 0.2
+    out = []
+    for priv in (1, 2, 0):  # privateTallies: 1 = automatic (grid in LDS too), 2 = tallies only, 0 = global atomics
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, intensityMus=[1.0, 0.4], intensityPhis=[0.0, 200.0], computeIntensity=True,
+                                useRussianRouletteForIntensity=True)
+        integ.setTuning(eventThreshold=16, privateTallies=priv)
+        photons = M.new_PhotonStream(0.6, 20.0, numberOfPhotons=10 ** 9)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, 20000, 2)
+        out.append(integ.moments().copy())
+        integ.finalize()
+    # (the LDS-resident walk stops at every face, the global-memory walk skips the clear layers: equal fluxes and
+    # radiances to rounding, so compare those two statistically and the two global-grid modes bitwise)
+    assert np.array_equal(out[1], out[2])
+    m = out[0].size // 2
+    assert np.allclose(out[0][8:8 + 3], out[1][8:8 + 3], rtol=2e-3)
