@@ -255,3 +255,44 @@ def test_radiance_is_independent_of_the_tally_mode(M):
     assert np.array_equal(out[1], out[2])
     m = out[0].size // 2
     assert np.allclose(out[0][8:8 + 3], out[1][8:8 + 3], rtol=2e-3)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ray_buffer_on_random_domains(M, seed, monkeypatch):
+    """Random small domains (equal or stretched spacing, random clear layers, one or two components, random views
+    incl. grazing ones, with and without roulette): long rays put aside vs finished in place, bitwise."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    rng = np.random.default_rng(500 + seed)
+    nx, ny, nz = int(rng.integers(2, 12)), int(rng.integers(1, 9)), int(rng.integers(4, 20))
+    def edges(n, stretched):
+        d = rng.uniform(0.02, 0.06) * (np.cumprod(rng.uniform(0.85, 1.2, n)) if stretched else np.ones(n))
+        return np.concatenate([[0.0], np.cumsum(d)])
+    xe, ye, ze = edges(nx, rng.random() < 0.4), edges(ny, rng.random() < 0.4), edges(nz, rng.random() < 0.5)
+    ext = rng.uniform(0.0, 20.0, (nx, ny, nz)) * (rng.random((nx, ny, nz)) < 0.6)
+    for k in np.nonzero(rng.random(nz) < 0.5)[0]:
+        ext[:, :, k] = rng.choice([0.0, rng.uniform(0.01, 2.0)])
+    comps = [dict(ext=ext, ssa=np.where(ext > 0, rng.uniform(0.7, 1.0), 0.0), pfIndex=np.ones(ext.shape, np.int32),
+                  legendre=[cases.hg_legendre(rng.uniform(0.3, 0.9), 32)])]
+    if rng.random() < 0.5:
+        comps.append(dict(ext=rng.uniform(0.0, 0.2, nz), ssa=np.ones(nz), pfIndex=np.ones(nz, np.int32),
+                          legendre=[np.array([0.0, 0.1], np.float32)]))
+    case = dict(name="rayrandom%d" % seed, xe=xe, ye=ye, ze=ze, albedo=float(rng.choice([0.0, 0.4])), components=comps)
+    rr = bool(rng.integers(0, 2))
+    ndir = int(rng.integers(1, 4))
+    mus = rng.uniform(0.05, 1.0, ndir) * (1.0 if rr else rng.choice([1.0, -1.0], ndir))  # (no roulette for downward views)
+    phis = rng.uniform(0.0, 360.0, ndir)
+    priv, mu0 = int(rng.integers(0, 3)), float(rng.uniform(0.1, 1.0))
+    out = {}
+    for defer in ("0", "1"):
+        monkeypatch.setenv("MCBRAT_RAY_DEFER", defer)
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, intensityMus=mus, intensityPhis=phis, computeIntensity=True,
+                                useRussianRouletteForIntensity=rr)
+        integ.setTuning(eventThreshold=24, privateTallies=priv)
+        photons = M.new_PhotonStream(mu0, 40.0, numberOfPhotons=10 ** 9)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED + seed), photons, 20000, 2)
+        out[defer] = integ.moments().copy()
+        integ.finalize()
+    assert np.array_equal(out["0"], out["1"]), case["name"]
