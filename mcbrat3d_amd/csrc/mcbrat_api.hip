@@ -486,9 +486,9 @@ int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatche
   if (c->nDir > 0) {
     if (DBG) return fail(c, "computeRadiativeTransfer: event counters / photon fates are not available together with intensity directions.");
     // the waves' buffers of unfinished long rays (80 B per ray) take what LDS is left at the residency the kernel is built
-    // for: 5 workgroups of 256 lanes per CU on grids in global memory, 2 workgroups otherwise
+    // for: 4 workgroups of 256 lanes per CU on grids in global memory, 2 workgroups otherwise
     const size_t waves = BLOCK / 64, base = (L.lds + 15) & ~(size_t)15;
-    const size_t budget = c->ldsPerCU / (L.priv ? 2 : (BLOCK == 256 ? 5 : 2));
+    const size_t budget = c->ldsPerCU / (L.priv ? 2 : (BLOCK == 256 ? 4 : 2));
     size_t cap = (c->rayDefer && budget > base + 64) ? std::min<size_t>(64, (budget - base - 64) / (waves * 80)) : 0;
     if (cap < 24 || c->nx + c->ny + c->nz + 3 > 0xffff || c->nDir > 0xffff) cap = 0;  // (a ray record packs edge-table indices and the direction in 16 bits)
     p.rayCap = (int)cap;
