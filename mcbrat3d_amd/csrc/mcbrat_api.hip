@@ -588,7 +588,8 @@ int check_ready(mcbrat_ctx *c) {
 int autotune(mcbrat_ctx *c, DevParams p, unsigned long long ppb, int nBatches) {
   // about 64 photons per resident lane: with fewer the synchronised start and the drain of the launch dominate
   // and favour too low a threshold
-  const unsigned long long want = c->tuneTrialPhotons;
+  // (radiance runs cost several times more per photon: fewer trial photons, so that the ten trial launches stay well under a second)
+  const unsigned long long want = c->tuneTrialPhotons / (unsigned long long)(1 + 2 * c->nDir);
   const unsigned long long total = ppb * (unsigned long long)nBatches;
   if (total < want) {
     // too few photons for a meaningful trial: a guess by domain size (few faces per leg on small grids, many on
