@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- photons/sec of the photon-tracing hot path on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py                       # N = 1, finishes in about a minute
+    python bench.py --gpus N              # starts its own N ranks (torch.distributed.run as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W      # or: launched by the driver
 
 One "step" = one complete job of the workload on every rank: the I3RC step cloud
 (BASELINE.json configs[1]: 32x1x32, tau 2|18, omega0 0.99, HG g 0.85, mu0 1) traced with
 1e7 photons per GPU as 100 batches of 1e5 (computeRadiativeTransfer + reportResults +
 batch moments on the device), followed by the all-reduce of the moment arrays over RCCL
-(the reference's sumAcrossProcesses).  Weak scaling: every rank traces its own 1e7
-photons per step (disjoint photon-id ranges of one Philox key).  Inputs (grids, tables)
-are resident in HBM before the timed region; photons are generated on the GPU.
+(the reference's sumAcrossProcesses, Drivers/monteCarloDriver.f95:1151-1166).  Weak scaling:
+every rank traces its own 1e7 photons per step (disjoint photon-id ranges of one Philox key).
+Inputs (grids, tables) are resident in HBM before the timed region; photons are generated on
+the GPU.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- algorithmic bytes of the tracing kernel / its HIP-event duration vs HBM peak
-  cpu_baseline -- the CPU oracle (a port of the reference loop, pinned to the reference's
-                  own outputs) timed on this box's host cores on a bounded photon sample
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     -- algorithmic bytes of the tracing kernel / its HIP-event duration vs HBM peak, the
+                  HBM traffic the counters saw, and -- because instruction issue, not HBM, is what
+                  binds this path -- a `valu` object (issue fraction, lane occupancy, wait split)
+  cpu_baseline -- the CPU oracle (a C restatement of the reference loop: "port") timed on this
+                  box's host cores on a bounded photon sample, with the measured speed ratio to the
+                  reference Fortran (calibration_r) and the reference-equivalent rate
+  parity       -- z-scores of the GPU's domain means, per-column fluxes and per-level heating
+                  against that CPU sample (oracle in MT mode: the reference's generator and draw order)
+  secondary    -- the 128x128x64 cloud field (the domain BASELINE.json's target is quoted on)
+
+--dry-run rehearses the launcher and the collective on CPU (gloo): no tracing, no GPU.
 """
 import argparse
 import json
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +44,8 @@ sys.path.insert(0, ROOT)
 
 from tests import cases  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0  # wave64 VALU instructions per second: 1024 SIMD-32s, one per 2 cycles, 2.4 GHz
 WORKLOADS = {
     # cpu: photons per host core of the cpu_baseline sample (about 20 s of oracle time), parity: photons of the GPU parity run
     "i3rcStepCloud": dict(make=lambda: cases.step_cloud(ssa=0.99), mu0=1.0, phi0=0.0, ppb=100000, batches=100,
@@ -65,15 +78,16 @@ def _cpu_worker(args):
     rng = O.mt_rng([10, proc, 0])
     src = O.solar_source(w["mu0"], w["phi0"])
     t = time.time()
-    means, cols, counters, done = [], [], None, 0
+    means, cols, prof, counters, done = [], [], [], None, 0
     while done < n:
         nb = min(CPU_BATCH, n - done)
         res = O.compute_radiative_transfer(P, src, rng, nb)
         means.append((nb, np.array([res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"]], np.float64)))
         cols.append((nb, np.concatenate([res["fluxUp"], res["fluxDown"], res["fluxAbsorbed"]]).astype(np.float64)))
+        prof.append((nb, np.asarray(res["absorbedProfile"], np.float64)))
         counters = res["counters"] if counters is None else {k: counters[k] + v for k, v in res["counters"].items()}
         done += nb
-    return time.time() - t, n, means, cols, counters
+    return time.time() - t, n, means, cols, counters, prof
 
 
 def cpu_baseline(name, photons_per_core, max_cores):
@@ -88,45 +102,220 @@ def cpu_baseline(name, photons_per_core, max_cores):
     busiest = max(o[0] for o in out)
     batches = [b for o in out for b in o[2]]
     cols = [b for o in out for b in o[3]]
+    prof = [b for o in out for b in o[5]]
     counters = {k: sum(o[4][k] for o in out) for k in out[0][4]}
-    return dict(value=total / busiest, unit="photons/s", cores=cores, kind="port",
-                sample="%d photons/core x %d cores of the same workload in batches of %d, oracle in MT mode "
-                       "(%.1f s wall)" % (photons_per_core, cores, CPU_BATCH, wall)), batches, cols, counters, total
+    cb = dict(value=total / busiest, unit="photons/s", cores=cores, kind="port",
+              sample="%d photons/core x %d cores of the same workload in batches of %d, oracle in MT mode "
+                     "(%.1f s wall)" % (photons_per_core, cores, CPU_BATCH, wall))
+    cal = os.path.join(ROOT, "profiles", "cpu_calibration.json")
+    if os.path.exists(cal):  # oracle vs reference Fortran, one core, same container (provenance in the file)
+        with open(cal) as f:
+            rec = json.load(f)
+        cb["calibration_r"] = rec["r"]
+        cb["reference_equivalent"] = cb["value"] / rec["r"]
+        cb["calibration_source"] = rec["source"]
+    return cb, batches, cols, counters, total, prof
 
 
-def secondary_workload(M, new_rng, name="landsatLike128", steps=3):
-    """Untimed extra (not the contract's metric): BASELINE.json's target is quoted on a 128x128x64 domain, so the
-    default single-GPU run also reports that workload's rate: `steps` synchronous steps of 1e8 photons after one
-    warm-up step (which also lets the library choose its event threshold)."""
+def z_scores(g, ge, r, re):
+    return (np.asarray(g) - np.asarray(r)) / np.sqrt(np.asarray(ge) ** 2 + np.asarray(re) ** 2 + 1e-30)
+
+
+def parity_block(stats, batches, cols, prof, ccnt, ctot):
+    """z = (GPU - REF) / sqrt(sigma_GPU^2 + sigma_REF^2), sigma from the batch variance
+    (the driver's estimator, monteCarloDriver.f95:1188-1219), over the domain means, every column flux and every
+    level of the absorption (heating) profile; pass = max |z| < 4 over the bins (5 beyond 10^4 bins: the largest
+    of N unit normals grows like sqrt(2 ln N)) and |mean z| < 0.2."""
+    from oracle import oracle as O
+    m_ref, e_ref = O.batch_statistics(batches)
+    c_ref, ce_ref = O.batch_statistics(cols)
+    p_ref, pe_ref = O.batch_statistics(prof)
+    g = np.array([stats["meanFluxUp"], stats["meanFluxDown"], stats["meanFluxAbsorbed"]])
+    ge = np.array([stats["meanFluxUp_StdErr"], stats["meanFluxDown_StdErr"], stats["meanFluxAbsorbed_StdErr"]])
+    z = z_scores(g, ge, m_ref, e_ref)
+    gc = np.concatenate([stats[k].T.reshape(-1) for k in ("fluxUp", "fluxDown", "fluxAbsorbed")])
+    gce = np.concatenate([stats[k + "_StdErr"].T.reshape(-1) for k in ("fluxUp", "fluxDown", "fluxAbsorbed")])
+    zc = z_scores(gc, gce, c_ref, ce_ref)
+    live = (np.asarray(stats["absorbedProfile_StdErr"]) > 0) | (pe_ref > 0)  # (levels nothing is absorbed in carry no statistic)
+    zp = z_scores(stats["absorbedProfile"], stats["absorbedProfile_StdErr"], p_ref, pe_ref)[live]
+    lim_c = 4.0 if zc.size <= 10000 else 5.0
+    ok = bool(np.max(np.abs(zc)) < lim_c and abs(np.mean(zc)) < 0.2 and (zp.size == 0 or np.max(np.abs(zp)) < 4.0)
+              and np.max(np.abs(z)) < 4.0)
+    return {"gpu_photons": int(stats["totalPhotons"]), "cpu_photons": int(ctot),
+            "max_abs_z_domain_mean": float(np.max(np.abs(z))), "z_domain_means": [float(x) for x in z],
+            "max_abs_z_column": float(np.max(np.abs(zc))), "mean_z_column": float(np.mean(zc)),
+            "std_z_column": float(np.std(zc)), "frac_abs_z_column_gt_3": float(np.mean(np.abs(zc) > 3)),
+            "n_column_bins": int(zc.size),
+            "max_abs_z_heating_level": float(np.max(np.abs(zp))) if zp.size else 0.0,
+            "mean_z_heating_level": float(np.mean(zp)) if zp.size else 0.0,
+            "std_z_heating_level": float(np.std(zp)) if zp.size else 0.0, "n_heating_levels": int(zp.size),
+            "thresholds": {"max_abs_z_bins": lim_c, "abs_mean_z": 0.2, "max_abs_z_levels": 4.0}, "within_thresholds": ok,
+            "gpu_means": [float(x) for x in g], "cpu_means": [float(x) for x in m_ref],
+            "cpu_events_per_photon": {k: v / ctot for k, v in ccnt.items() if k != "draws"}}
+
+
+def pmc_record(workload):
+    """Counter figures of the shipped kernel for this workload (profiles/pmc_shipped.json, written by
+    scripts/pmc_summary.py from separate rocprofv3 --pmc passes; per launch of photons_per_launch photons)."""
+    path = os.path.join(ROOT, "profiles", "pmc_shipped.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f).get(workload, {})
+
+
+def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False):
+    bpp = algorithmic_bytes_per_photon(cnt, per_step, nc)
+    achieved = bpp * per_step / (launch_ms * 1e-3) / 1e9
+    rec = pmc_record(workload)
+    scale = per_step / rec.get("photons_per_launch", per_step)
+    traffic = rec["hbm_bytes_per_launch"] * scale if rec.get("hbm_bytes_per_launch") is not None else None
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "achieved_is": "algorithmic bytes (SURVEY.md 8d) / kernel time: an equivalent rate, not HBM utilisation",
+           "measured_hbm_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic is not None else None,
+           "algorithmic_bytes_per_photon": bpp, "kernel": "trace_kernel", "kernel_ms_per_launch": launch_ms,
+           "events_per_photon": {k: v / per_step for k, v in cnt.items() if k in (
+               "legs", "crossings", "collisions", "absorbEvents", "topExits", "surfaceHits", "rouletteKills", "rouletteSurvivals")},
+           "lanes_per_walk_iteration": cnt["walkLanes"] / max(1, cnt["walkIterations"]),
+           "lanes_per_event_phase": cnt["eventLanes"] / max(1, cnt["eventPhases"]),
+           "binding_resource": "valu_issue" if workload == "i3rcStepCloud" else "l2_requests",
+           "note": "working set is cache / LDS resident: HBM is not what binds (see valu); DESIGN.md section 5"
+                   + ("; --pipeline: kernel durations include waiting for compute units held by the previous launch" if pipeline else "")}
+    if rec.get("valu_insts_per_launch"):
+        # VALU issue fraction from THIS run's kernel time and the instruction count the counters saw for the same launch shape
+        insts = rec["valu_insts_per_launch"] * scale
+        out["valu"] = {"issue_frac": insts / (launch_ms * 1e-3) / VALU_ISSUE_PEAK, "peak_wave_insts_per_s": VALU_ISSUE_PEAK,
+                       "valu_wave_insts_per_photon": insts / per_step, "lane_occupancy": rec.get("lane_occupancy"),
+                       "useful_lane_cycle_frac": (insts / (launch_ms * 1e-3) / VALU_ISSUE_PEAK) * (rec.get("lane_occupancy") or 0.0),
+                       "wave_time_issuing": rec.get("wave_time_issuing"), "wave_time_waiting": rec.get("wave_time_waiting"),
+                       "wave_time_issue_stall": rec.get("wave_time_issue_stall"),
+                       "lds_bank_conflict_ratio": rec.get("lds_bank_conflict_ratio"),
+                       "l2_requests_per_photon": (rec.get("l2_requests_per_launch") or 0.0) / rec.get("photons_per_launch", per_step),
+                       "l2_hit_rate": rec.get("l2_hit_rate"), "source": rec.get("source")}
+    return out
+
+
+def secondary_workload(M, new_rng, device, dist, rank, world, name="landsatLike128", steps=3):
+    """Not the contract's metric: BASELINE.json's target is quoted on a 128x128x64 domain, so every run also reports
+    that workload's whole-job rate: `steps` synchronous steps of 1e8 photons per GPU (each followed by the all-reduce
+    of the moments when there are several ranks) after one warm-up step, which also lets the library choose its
+    event threshold."""
+    import torch
     w = WORKLOADS[name]
     dom = cases.product_domain(w["make"]())
-    integ = M.new_Integrator(dom)
+    integ = M.new_Integrator(dom, device=device)
     integ.specifyParameters(minInverseTableSize=10001, useRayTracing=True, useRussianRoulette=True)
     photons = M.new_PhotonStream(w["mu0"], w["phi0"], numberOfPhotons=10 ** 15)
     rng = new_rng(10)
-    integ.resetMoments()
-    integ.computeRadiativeTransfer(dom, rng, photons, w["ppb"], w["batches"])
-    integ.synchronize()
-    t0, kms = time.perf_counter(), 0.0
-    for _ in range(steps):
+    per_step = w["ppb"] * w["batches"]
+    dev = torch.device("cuda", device)
+    moments = torch.zeros(8 + 2 * integ.momentsLength(), dtype=torch.float64, device=dev)
+    integ.bindMoments(moments.data_ptr())
+
+    def step(i):
+        rng.nextPhotonId = (i * world + rank) * per_step
+        photons.currentPhoton = 1
         integ.resetMoments()
         integ.computeRadiativeTransfer(dom, rng, photons, w["ppb"], w["batches"])
-        kms += integ.lastTraceMs()
+        if dist is not None:
+            dist.all_reduce(moments, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        return integ.lastTraceMs()
+
+    step(0)
     integ.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0, kms = time.perf_counter(), 0.0
+    for i in range(steps):
+        kms += step(1 + i)
+    integ.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    integ.enableCounters(True)
-    integ.computeRadiativeTransfer(dom, rng, photons, w["ppb"], 10)
-    cnt = integ.counters()
-    integ.enableCounters(False)
-    per_step = w["ppb"] * w["batches"]
-    bpp = algorithmic_bytes_per_photon(cnt, w["ppb"] * 10, len(dom.components))
-    achieved = bpp * per_step / (kms / steps * 1e-3) / 1e9
-    res = {"workload": "%s %dx%dx%d, %d photons/step" % (name, dom.numX, dom.numY, dom.numZ, per_step),
-           "value": per_step * steps / dt, "unit": "photons/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
-           "kernel_ms_per_launch": kms / steps, "algorithmic_bytes_per_photon": bpp,
-           "roofline_frac": achieved / HBM_PEAK_GBS, "event_threshold": integ.eventThreshold()}
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    res = None
+    if rank == 0:
+        integ.bindMoments(0)
+        integ.enableCounters(True)
+        integ.computeRadiativeTransfer(dom, rng, photons, w["ppb"], 10)
+        cnt = integ.counters()
+        integ.enableCounters(False)
+        rl = roofline_block(name, cnt, w["ppb"] * 10, len(dom.components), kms / steps * 0.1)
+        res = {"workload": "%s %dx%dx%d, %d photons/GPU/step" % (name, dom.numX, dom.numY, dom.numZ, per_step),
+               "value": world * per_step * steps / dt, "unit": "photons/s", "n_gpus": world, "steps": steps,
+               "ms_per_step": 1e3 * dt / steps, "kernel_ms_per_launch": kms / steps,
+               "algorithmic_bytes_per_photon": rl["algorithmic_bytes_per_photon"], "roofline_frac": rl["frac"],
+               "roofline": rl, "event_threshold": integ.eventThreshold()}
     integ.finalize()
     return res
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD process (torch.distributed.run, one
+    process per GPU) and pass its output through.  Nothing in this process has touched the GPU -- torch is not even
+    imported yet -- and nothing is exec'ed: the child's exit code is returned."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    env["BENCH_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(a, rank, world):
+    """Launcher / collective rehearsal on CPU: gloo, no tracing, no GPU.  Every rank contributes a moments-shaped
+    array with its rank in it; rank 0 prints ONE JSON line with the ranks it saw."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    sys.stdout.flush()
+    saved_fd = os.dup(1)  # (gloo announces its connections on stdout; the contract is ONE JSON line there)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    w = WORKLOADS[a.workload]
+    per_step = w["ppb"] * w["batches"]
+    seen = torch.zeros(world, dtype=torch.float64)
+    seen[rank] = 1.0 + rank
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.warmup + a.steps):
+        buf = torch.zeros(8 + 2 * 16, dtype=torch.float64)
+        buf[0], buf[1] = per_step, w["batches"]
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)  # sumAcrossProcesses
+    dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "photons/sec", "value": 0.0, "unit": "photons/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": 1e3 * float(tt.item()) / max(1, a.steps), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": a.workload, "world_size": dist.get_world_size(), "backend": "gloo",
+                                     "ranks_seen": [int(x) - 1 for x in seen.tolist()],
+                                     "photons_all_ranks_per_step": int(buf[0].item())}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -138,19 +327,28 @@ def main():
     ap.add_argument("--cpu-photons-per-core", type=int, default=0, help="0 = the workload's default")
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed 128x128x64 extra of the default run")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed 128x128x64 extra")
     ap.add_argument("--parity-photons", type=int, default=0, help="0 = the workload's default")
     ap.add_argument("--event-threshold", type=int, default=0,
                     help="0 = let the library time trial launches (default); >0 fixes it (profiling runs)")
+    ap.add_argument("--block-walk", type=int, default=-1, help="-1 library default; 0 face-by-face walk; 1 block walk")
     ap.add_argument("--pipeline", action="store_true",
                     help="let consecutive steps overlap on the GPU (asynchronous mode of the library: hides each "
                          "launch's drain; per-kernel durations then include time spent waiting for compute units, so "
                          "the default run, whose kernel durations rocprofv3 must reproduce, does not use it)")
+    ap.add_argument("--dry-run", action="store_true", help="rehearse launcher + collective on CPU (gloo), no tracing")
     a = ap.parse_args()
 
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if a.gpus > 1 and not under_launcher:
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if under_launcher and a.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (a.gpus, world, world), file=sys.stderr)
+    if a.dry_run:
+        return dry_run(a, rank, world)
     if world > 1:
         a.no_cpu_baseline = True  # the CPU baseline (and the parity check against it) belongs to the N = 1 line
     import torch
@@ -191,7 +389,7 @@ def main():
     nc = len(dom.components)
     integ = M.new_Integrator(dom, device=local_rank)
     integ.specifyParameters(minInverseTableSize=10001, useRayTracing=True, useRussianRoulette=True)
-    integ.setTuning(eventThreshold=a.event_threshold)
+    integ.setTuning(eventThreshold=a.event_threshold, blockWalk=a.block_walk)
     photons = M.new_PhotonStream(w["mu0"], w["phi0"], numberOfPhotons=10 ** 15)
     ppb, nb = w["ppb"], w["batches"]
     per_step = ppb * nb
@@ -241,18 +439,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    out = None
     if rank == 0:
         # the moment arrays now hold the last step: world * per_step photons, reduced over ranks
         stats = driver.statistics(driver.unpack_moments(moments.cpu().numpy(), nx, ny, nz))
-        # untimed: event counters (instrumented kernel) on one step's worth of photons
+        reduced_photons = int(stats["totalPhotons"])
         integ.bindMoments(0)
         if not a.no_cpu_baseline:
-            # untimed parity run: 1e8 photons (BASELINE.json's accuracy target is quoted at 1e8)
+            # untimed parity run (BASELINE.json's accuracy target is quoted at 1e8 photons)
             integ.resetMoments()
             rng.nextPhotonId = 10 ** 12
             photons.currentPhoton = 1
             integ.computeRadiativeTransfer(dom, rng, photons, ppb, a.parity_photons // ppb)
             stats = driver.statistics(driver.unpack_moments(integ.moments(), nx, ny, nz))
+        # untimed: event counters (instrumented kernel) on one step's worth of photons
         integ.resetMoments()
         integ.enableCounters(True)
         rng.nextPhotonId = 0
@@ -260,16 +460,7 @@ def main():
         integ.computeRadiativeTransfer(dom, rng, photons, ppb, nb)
         cnt = integ.counters()
         integ.enableCounters(False)
-        bpp = algorithmic_bytes_per_photon(cnt, per_step, nc)
         launch_ms = kernel_ms / a.steps
-        achieved = bpp * per_step / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                rec = json.load(f).get(a.workload, {})
-            if rec.get("hbm_bytes_per_launch") is not None:  # counters were collected on launches of photons_per_launch photons
-                traffic = rec["hbm_bytes_per_launch"] * per_step / rec.get("photons_per_launch", per_step)
         out = {
             "metric": "photons/sec", "value": world * per_step * a.steps / elapsed, "unit": "photons/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -278,38 +469,22 @@ def main():
             "config": {"workload": "%s %dx%dx%d, %d photons/GPU/step as %d batches x %d, omega0=0.99 HG g=0.85 mu0=%g"
                        % (a.workload, nx, ny, nz, per_step, nb, ppb, w["mu0"]),
                        "photons_per_step_per_gpu": per_step, "parallelism": "photon batches sharded over %d GPU(s)" % world,
-                       "pipelined_steps": bool(a.pipeline), "event_threshold": integ.eventThreshold()},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_photon": bpp, "kernel": "trace_kernel", "kernel_ms_per_launch": launch_ms,
-                         "events_per_photon": {k: v / per_step for k, v in cnt.items() if k in ("legs", "crossings", "collisions", "absorbEvents", "topExits", "surfaceHits", "rouletteKills", "rouletteSurvivals")},
-                         "lanes_per_walk_iteration": cnt["walkLanes"] / max(1, cnt["walkIterations"]),
-                         "lanes_per_event_phase": cnt["eventLanes"] / max(1, cnt["eventPhases"]),
-                         "note": "working set is cache resident; the path is latency/VALU bound (DESIGN.md)"
-                                 + ("; --pipeline: kernel durations include waiting for compute units held by the previous launch" if a.pipeline else "")},
+                       "world_size": dist.get_world_size() if dist is not None else 1,
+                       "photons_in_reduced_moments_last_step": reduced_photons,
+                       "pipelined_steps": bool(a.pipeline), "event_threshold": integ.eventThreshold(),
+                       "walk": integ.walkMode()},
+            "roofline": roofline_block(a.workload, cnt, per_step, nc, launch_ms, a.pipeline),
         }
         if not a.no_cpu_baseline:
-            cb, batches, cols, ccnt, ctot = cpu_baseline(a.workload, a.cpu_photons_per_core, a.cpu_cores)
+            cb, batches, cols, ccnt, ctot, prof = cpu_baseline(a.workload, a.cpu_photons_per_core, a.cpu_cores)
             out["cpu_baseline"] = cb
-            # flux error vs the CPU reference path, in units of the combined Monte Carlo sigma
-            from oracle import oracle as O
-            m_ref, e_ref = O.batch_statistics(batches)
-            c_ref, ce_ref = O.batch_statistics(cols)
-            g = np.array([stats["meanFluxUp"], stats["meanFluxDown"], stats["meanFluxAbsorbed"]])
-            ge = np.array([stats["meanFluxUp_StdErr"], stats["meanFluxDown_StdErr"], stats["meanFluxAbsorbed_StdErr"]])
-            z = (g - m_ref) / np.sqrt(ge ** 2 + e_ref ** 2 + 1e-30)
-            gc = np.concatenate([stats[k].T.reshape(-1) for k in ("fluxUp", "fluxDown", "fluxAbsorbed")])
-            gce = np.concatenate([stats[k + "_StdErr"].T.reshape(-1) for k in ("fluxUp", "fluxDown", "fluxAbsorbed")])
-            zc = (gc - c_ref) / np.sqrt(gce ** 2 + ce_ref ** 2 + 1e-30)
-            out["parity"] = {"gpu_photons": int(stats["totalPhotons"]), "cpu_photons": int(ctot),
-                             "max_abs_z_domain_mean": float(np.max(np.abs(z))),
-                             "max_abs_z_column": float(np.max(np.abs(zc))), "mean_z_column": float(np.mean(zc)),
-                             "std_z_column": float(np.std(zc)), "frac_abs_z_column_gt_3": float(np.mean(np.abs(zc) > 3)),
-                             "n_column_bins": int(zc.size),
-                             "gpu_means": [float(x) for x in g], "cpu_means": [float(x) for x in m_ref],
-                             "cpu_events_per_photon": {k: v / ctot for k, v in ccnt.items() if k != "draws"}}
-        if world == 1 and a.workload == "i3rcStepCloud" and not a.no_secondary:
-            out["secondary"] = secondary_workload(M, new_RandomNumberSequence)
+            out["parity"] = parity_block(stats, batches, cols, prof, ccnt, ctot)
+    integ.finalize()
+    if a.workload == "i3rcStepCloud" and not a.no_secondary:  # every rank takes part (all-reduce inside)
+        sec = secondary_workload(M, new_RandomNumberSequence, local_rank, dist if world > 1 else None, rank, world)
+        if rank == 0:
+            out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -201,11 +201,12 @@ int mcbrat_set_surface_description(mcbrat_ctx *ctx, int32_t numX, int32_t numY, 
  * accumulateExtinctionAlongPath (src/opticalProperties.f95:1697-1814) stops at every x and y face too, which changes
  * nothing inside such a layer but the float rounding of the accumulated optical depth; 0 restores that face-by-face
  * walk (used by the per-photon identity tests).
- * exchange (default 0, experimental): flux runs with the directional source use the photon-exchange form of the
- * tracing kernel (mcbrat_exchange.hip: photons move between waves at leg boundaries through LDS queues, so that
- * walking and event processing both run with nearly all lanes busy).  Results are bitwise those of the
- * one-photon-per-lane kernel; it is not faster on the workloads measured so far. */
-int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t exchange);
+ * blockWalk (default 1): domains whose optical grid is resident in LDS (I3RC step cloud, plane-parallel and other
+ * small domains): the grid is cut into axis-aligned blocks of cells that carry one extinction value, and a leg goes
+ * from block face to block face instead of from cell face to cell face; the cell of a collision or an exit is found
+ * from the position.  Same argument as for layerSkip: inside a block the reference's stops at cell faces only add
+ * `segment x the same extinction` again.  0 restores the face-by-face walk. */
+int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t blockWalk);
 
 /* The event threshold in use (after the first call of a domain: the one chosen by the trial launches). */
 int mcbrat_get_event_threshold(const mcbrat_ctx *ctx);

@@ -12,7 +12,6 @@
 #include <vector>
 
 #include "mcbrat_kernels.hip"
-#include "mcbrat_exchange.hip"
 
 using namespace mcbrat;
 
@@ -27,9 +26,9 @@ struct mcbrat_ctx {
     hipEvent_t evDone = nullptr;              // after the finish kernels of the lane's latest call
     unsigned long long *dCounter = nullptr;
     long long *dSlabs = nullptr;
-    size_t slabCapacity = 0;  // batches
+    size_t slabCapacity = 0;  // ELEMENTS allocated (not batches: the stride changes with nc, nDir and the grid)
     float *dColVals = nullptr, *dScalVals = nullptr;
-    size_t finishCapacity = 0;
+    size_t colCapacity = 0, scalCapacity = 0;  // elements allocated
   };
   static constexpr int kLanes = 4;
   Lane lane[kLanes];
@@ -113,10 +112,9 @@ struct mcbrat_ctx {
   unsigned long long tuneTrialPhotons = 1ull << 24;  // MCBRAT_TUNE_PHOTONS
   int regularWalk = 1;         // equally spaced grids: incremental face distances (MCBRAT_REGULAR_WALK=0 turns it off)
   int gridLdsMode = 1;         // stage the optical grid in LDS when it fits (private-tally mode)
-  int exchangeMode = 0;        // photon-exchange form of the tracing kernel where it applies: opt-in (MCBRAT_EXCHANGE=1 / mcbrat_set_walk_options), see DESIGN.md
-  int flushLanes = 16;         // exchange kernel: lanes of a wave that have stopped before it hands legs over (MCBRAT_FLUSH_LANES)
   int rayShort = 0, rayPassIters = 0, rayPassAt = 0;  // 0: chosen in launch_trace_b (MCBRAT_RAY_SHORT, MCBRAT_RAY_PASS_ITERS, MCBRAT_RAY_PASS_AT)
   int rayDefer = 1;            // radiance: long rays are put aside and finished in dense passes (MCBRAT_RAY_DEFER=0: inside their event phase)
+  int blockWalk = 1;           // LDS-resident grids: blocks of cells with one extinction value are crossed in one step (MCBRAT_BLOCK_WALK=0 / mcbrat_set_walk_options)
   int layerSkip = 1;           // layers of one extinction value: cross z faces only (MCBRAT_LAYER_SKIP=0 / mcbrat_set_walk_options)
   bool countersOn = false;
   float lastTraceMs = 0.f;
@@ -516,54 +514,12 @@ int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatche
                   : launch_trace_t<BLOCK, false, 0, false, DBG>(c, p, L.lds, nBatches);
 }
 
-// Photon-exchange form of the tracing kernel (mcbrat_exchange.hip): workgroups of 512 lanes, 11/8 photon slots per lane.
-constexpr int kXBlock = 512, kXSlots = 704;
-size_t exchange_lds(const LaunchPlan &L) { return ((L.lds + 15) & ~(size_t)15) + 32 + 3 * kXCells * sizeof(unsigned) + (size_t)kXSlots * 80; }
-
-bool exchange_applies(const mcbrat_ctx *c, const LaunchPlan &L, bool debug) {
-#ifdef MCBRAT_XSTATS
-  debug = false;  // (the stats build reports through the counters of an instrumented call)
-#endif
-  return c->exchangeMode == 1 && !debug && c->nDir == 0 && c->surfNumX == 0 && !L.brick && c->srcKind == 0 && !(c->lwFlag > 0.f) &&
-         c->nx <= 1024 && c->ny <= 1024 && c->nz <= 1024 && exchange_lds(L) <= (size_t)c->ldsPerCU;
-}
-
-template <bool TBL, int PRIV>
-int launch_trace_x(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatches) {
-  const size_t lds = exchange_lds(L);
-  auto kernel = trace_kernel_x<kXBlock, TBL, PRIV>;
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int perCU = c->blocksPerCU;
-  if (perCU <= 0) {
-    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kXBlock, lds));
-    perCU = std::max(1, std::min(perCU, 8));
-  }
-  unsigned long long blocks = (unsigned long long)perCU * c->numCUs;
-  if (PRIV) {
-    unsigned long long upb = std::max<unsigned long long>(1, blocks / (unsigned long long)nBatches);
-    upb = std::min<unsigned long long>(upb, std::max<unsigned long long>(1, p.ppb / (unsigned long long)(kXBlock * 8)));
-    p.unitsPerBatch = upb;
-    p.nUnits = upb * (unsigned long long)nBatches;
-    blocks = std::min(blocks, p.nUnits);
-  } else {
-    blocks = std::min(blocks, (p.total + kXBlock - 1) / kXBlock);
-  }
-  hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<unsigned long long>(1, blocks)), dim3(kXBlock), lds, c->L().stream, p, kXSlots, c->flushLanes);
-  HIP_OK(c, hipGetLastError());
-  return 0;
-}
-
 int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   LaunchPlan L = plan_launch(c, (size_t)p.slabStride);
   if (L.priv && L.brick) {  // fill_params chose the brick arrays: private tallies give way
     L.priv = false;
     L.gridLds = false;
     L.lds = plan_launch_lds(c, L);
-  }
-  if (exchange_applies(c, L, debug)) {
-    if (L.priv && L.gridLds) return L.tblLds ? launch_trace_x<true, 2>(c, p, L, nBatches) : launch_trace_x<false, 2>(c, p, L, nBatches);
-    if (L.priv) return L.tblLds ? launch_trace_x<true, 1>(c, p, L, nBatches) : launch_trace_x<false, 1>(c, p, L, nBatches);
-    return L.tblLds ? launch_trace_x<true, 0>(c, p, L, nBatches) : launch_trace_x<false, 0>(c, p, L, nBatches);
   }
   // small domains (grid, tables and tallies in LDS): LDS holds two workgroups per CU, and two workgroups of 12 waves
   // (6 per SIMD, 80 VGPRs) beat two of 8 (4 per SIMD, no spills) by 10 % on the step cloud (640 and 896 lanes lose)
@@ -636,12 +592,11 @@ mcbrat_ctx *mcbrat_create(int device) {
   c->device = device;
   if (const char *e = getenv("MCBRAT_REGULAR_WALK")) c->regularWalk = atoi(e);
   if (const char *e = getenv("MCBRAT_LAYER_SKIP")) c->layerSkip = atoi(e);
+  if (const char *e = getenv("MCBRAT_BLOCK_WALK")) c->blockWalk = atoi(e);
   if (const char *e = getenv("MCBRAT_RAY_DEFER")) c->rayDefer = atoi(e);
   if (const char *e = getenv("MCBRAT_RAY_SHORT")) c->rayShort = std::max(1, atoi(e));
   if (const char *e = getenv("MCBRAT_RAY_PASS_ITERS")) c->rayPassIters = std::max(1, atoi(e));
   if (const char *e = getenv("MCBRAT_RAY_PASS_AT")) c->rayPassAt = std::max(1, atoi(e));
-  if (const char *e = getenv("MCBRAT_EXCHANGE")) c->exchangeMode = atoi(e);
-  if (const char *e = getenv("MCBRAT_FLUSH_LANES")) c->flushLanes = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_TUNE_PHOTONS")) c->tuneTrialPhotons = strtoull(e, nullptr, 10);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -711,9 +666,12 @@ int mcbrat_set_grid(mcbrat_ctx *c, int32_t nx, int32_t ny, int32_t nz, const dou
       rel[(size_t)i + (size_t)nx * j] = (float)(((ye[j + 1] - ye[j]) * (xe[i + 1] - xe[i])) / ((xe[nx] - xe[0]) * (ye[ny] - ye[0])));
   if (upload(c, &c->dRelArea, rel.data(), rel.size())) return 1;
   c->haveGrid = true; c->haveOptics = false; c->haveSource = false; c->haveLast = false; c->tuned = false;
+  // everything sized by the old grid goes: the moment arrays, the last batch's results (the finish kernels write
+  // moments_len() elements of it), and the per-lane buffers are re-sized by the next call (their capacities are
+  // kept in elements and compared with what that call needs)
   if (c->dMomentsOwned) { (void)hipFree(c->dMomentsOwned); c->dMomentsOwned = nullptr; }
   c->dMoments = nullptr;
-  for (mcbrat_ctx::Lane &L : c->lane) L.slabCapacity = L.finishCapacity = 0;  // buffers are re-sized by the next call
+  if (c->dLast) { (void)hipFree(c->dLast); c->dLast = nullptr; }
   return 0;
 }
 
@@ -941,15 +899,12 @@ int mcbrat_specify_intensity(mcbrat_ctx *c, int32_t nDirections, const float *mu
     for (int a = 0; a < 3; ++a) d[4 + a] = std::fabs(d[a]) >= 2.0f * FLT_MIN ? 1.0f / d[a] : 0.0f;
   }
   const int limit = (limitIntensityContributions && maxIntensityContribution < FLT_MAX) ? 1 : 0;
-  if (limit != c->limitContrib)  // the batch slabs change length
-    for (mcbrat_ctx::Lane &L : c->lane) L.slabCapacity = L.finishCapacity = 0;
-  c->limitContrib = limit;
+  c->limitContrib = limit;  // (the batch slabs change length: the next call compares element counts)
   c->maxContrib = maxIntensityContribution;
   if (nDirections != c->nDir) {  // the moment arrays change length: start them afresh
     if (c->dMomentsOwned) { (void)hipFree(c->dMomentsOwned); c->dMomentsOwned = nullptr; }
     c->dMoments = nullptr;
     if (c->dLast) { (void)hipFree(c->dLast); c->dLast = nullptr; }
-    for (mcbrat_ctx::Lane &L : c->lane) L.slabCapacity = L.finishCapacity = 0;
     c->haveLast = false;
     c->tuned = false;
   }
@@ -1053,10 +1008,10 @@ int mcbrat_set_surface_description(mcbrat_ctx *c, int32_t numX, int32_t numY, co
   return 0;
 }
 
-int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip, int32_t exchange) {
+int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip, int32_t blockWalk) {
   if (!c) return 1;
   if (layerSkip >= 0) { if ((layerSkip != 0) != (c->layerSkip != 0)) c->tuned = false; c->layerSkip = layerSkip ? 1 : 0; }
-  if (exchange >= 0) { if ((exchange != 0) != (c->exchangeMode != 0)) c->tuned = false; c->exchangeMode = exchange ? 1 : 0; }
+  if (blockWalk >= 0) { if ((blockWalk != 0) != (c->blockWalk != 0)) c->tuned = false; c->blockWalk = blockWalk ? 1 : 0; }
   return 0;
 }
 
@@ -1090,21 +1045,26 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   for (int li = 0; li < mcbrat_ctx::kLanes; ++li) {
     mcbrat_ctx::Lane &L = c->lane[li];
     if (li != c->cur && !(c->asyncOn && L.stream)) continue;
-    if (L.slabCapacity >= inFlight && L.finishCapacity >= inFlight) continue;
+    const size_t needSlab = slabStride * inFlight, needCol = 3 * ncol * inFlight, needScal = (size_t)(3 + c->nz) * inFlight;
+    if (L.slabCapacity >= needSlab && L.colCapacity >= needCol && L.scalCapacity >= needScal) continue;
     HIP_OK(c, hipStreamSynchronize(L.stream));
-    if (L.slabCapacity < inFlight) {
+    if (L.slabCapacity < needSlab) {
       if (L.dSlabs) (void)hipFree(L.dSlabs);
-      L.dSlabs = nullptr;
-      HIP_OK(c, hipMalloc((void **)&L.dSlabs, sizeof(long long) * slabStride * inFlight));
-      L.slabCapacity = inFlight;
+      L.dSlabs = nullptr; L.slabCapacity = 0;
+      HIP_OK(c, hipMalloc((void **)&L.dSlabs, sizeof(long long) * needSlab));
+      L.slabCapacity = needSlab;
     }
-    if (L.finishCapacity < inFlight) {
+    if (L.colCapacity < needCol) {
       if (L.dColVals) (void)hipFree(L.dColVals);
+      L.dColVals = nullptr; L.colCapacity = 0;
+      HIP_OK(c, hipMalloc((void **)&L.dColVals, sizeof(float) * needCol));
+      L.colCapacity = needCol;
+    }
+    if (L.scalCapacity < needScal) {
       if (L.dScalVals) (void)hipFree(L.dScalVals);
-      L.dColVals = L.dScalVals = nullptr;
-      HIP_OK(c, hipMalloc((void **)&L.dColVals, sizeof(float) * 3 * ncol * inFlight));
-      HIP_OK(c, hipMalloc((void **)&L.dScalVals, sizeof(float) * (3 + c->nz) * inFlight));
-      L.finishCapacity = inFlight;
+      L.dScalVals = nullptr; L.scalCapacity = 0;
+      HIP_OK(c, hipMalloc((void **)&L.dScalVals, sizeof(float) * needScal));
+      L.scalCapacity = needScal;
     }
   }
   if (!c->dLast) HIP_OK(c, hipMalloc((void **)&c->dLast, sizeof(float) * (size_t)moments_len(c)));
@@ -1168,19 +1128,6 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   if (c->countersOn) {
     unsigned long long h[16];
     HIP_OK(c, hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost));
-#ifdef MCBRAT_XSTATS  // development aid: the exchange kernel's sections
-    if (c->exchangeMode) {
-      unsigned long long st[16];
-      HIP_OK(c, hipMemcpy(st, c->dEventCounters + 16, sizeof(st), hipMemcpyDeviceToHost));
-      const char *names[6] = {"refill", "walk", "flush", "event pass", "launch pass", "idle"};
-      double tot = 0;
-      for (int i = 0; i < 6; i++) tot += (double)st[i];
-      for (int i = 0; i < 6; i++) fprintf(stderr, "xstat %-12s %14llu  %5.1f %%\n", names[i], st[i], 100.0 * (double)st[i] / tot);
-      fprintf(stderr, "xstat walk iterations %llu, lanes/iteration %.1f | flushes %llu, lanes/flush %.1f | event passes %llu, lanes/pass %.1f | launch passes %llu, lanes/pass %.1f\n",
-              st[6], (double)st[7] / (double)std::max(1ull, st[6]), st[8], (double)st[9] / (double)std::max(1ull, st[8]), st[10],
-              (double)st[11] / (double)std::max(1ull, st[10]), st[12], (double)st[13] / (double)std::max(1ull, st[12]));
-    }
-#endif
 #ifdef MCBRAT_STAMPS  // development aid: wave cycles per section of the tracing loop
     {
       unsigned long long st[16];

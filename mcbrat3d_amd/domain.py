@@ -19,6 +19,7 @@ class Domain:
                 raise McbratError("new_Domain: %s positions must be increasing, unique." % n)  # :470-476
         if not (0.0 <= surfaceAlbedo <= 1.0):
             raise McbratError("new_Domain: surfaceAlbedo must be between 0 and 1.")
+        self._version = 0  # bumped by whatever changes the optics: integrators re-upload when it moves
         self.surfaceAlbedo = float(surfaceAlbedo)
         self.lambda_um = float(lambda_um)
         self.numX, self.numY, self.numZ = len(self.xPosition) - 1, len(self.yPosition) - 1, len(self.zPosition) - 1
@@ -27,6 +28,17 @@ class Domain:
         self.totalExt = self.cumulativeExt = self.ssa = self.phaseFunctionIndex = None
         self.forwardTables = []
         self.inversePhaseFunctions = None
+
+    @property
+    def surfaceAlbedo(self):
+        return self._surfaceAlbedo
+
+    @surfaceAlbedo.setter
+    def surfaceAlbedo(self, value):
+        if not (0.0 <= value <= 1.0):
+            raise McbratError("new_Domain: surfaceAlbedo must be between 0 and 1.")
+        self._surfaceAlbedo = float(value)
+        self._version += 1
 
     # addOpticalComponent3D / 1D (:554-700) with validateOpticalComponent (:1530-1591)
     def addOpticalComponent(self, componentName, extinction, singleScatteringAlbedo, phaseFunctionIndex,
@@ -56,6 +68,7 @@ class Domain:
                                     zLevelBase=int(zLevelBase)))
         self.totalExt = None  # expansion is stale
         self.inversePhaseFunctions = None
+        self._version += 1
 
     def getOpticalPropertiesByComponent(self):
         """:966-1072: per-component fields expanded to (x, y, z, component)."""

@@ -74,9 +74,22 @@ def run(integrator, domain, photons, numPhotonsPerBatch, numBatches, randomNumbe
     randomNumbers.nextPhotonId = first + numBatches * numPhotonsPerBatch
     if dist is not None and world > 1:
         import torch
-        torch.cuda.synchronize()
-        dist.all_reduce(moments_tensor, op=dist.ReduceOp.SUM)  # sumAcrossProcesses, :1151-1166
-        torch.cuda.synchronize()
+        if moments_tensor.is_cuda:
+            if moments_tensor.device.index != integrator.device:
+                raise ValueError("driver.run: moments_tensor lives on cuda:%s, the integrator on cuda:%d"
+                                 % (moments_tensor.device.index, integrator.device))
+            # The library runs on HIP streams of its own: the all-reduce is ordered after the finish kernels of the
+            # calls enqueued so far (also in asynchronous mode, where computeRadiativeTransfer returns before they
+            # ran), and the next write to the moments after the all-reduce -- by events, not by a device-wide
+            # synchronisation of whichever device happens to be torch's current one.
+            stream = torch.cuda.current_stream(moments_tensor.device).cuda_stream
+            integrator.streamWaitDone(stream)
+            dist.all_reduce(moments_tensor, op=dist.ReduceOp.SUM)  # sumAcrossProcesses, :1151-1166
+            integrator.waitStream(stream)
+            torch.cuda.synchronize(moments_tensor.device)
+        else:  # (gloo rehearsal on CPU tensors: tests/test_multi_rank.py)
+            integrator.synchronize()
+            dist.all_reduce(moments_tensor, op=dist.ReduceOp.SUM)
         buf = moments_tensor.cpu().numpy()
     else:
         buf = integrator.moments()

@@ -18,6 +18,7 @@ class Weights:
 
     def __init__(self, numX, numY, numZ, numLambda=1):
         self.numX, self.numY, self.numZ, self.numLambda = numX, numY, numZ, numLambda
+        self._version = 0  # bumped by emission_weighting: integrators re-upload the voxel CDF when it moves
         self.voxelWeights = None
         self.fracAtmsPower = 0.0
         self.spectrIntgrFlux = 0.0
@@ -47,6 +48,7 @@ def emission_weighting(thisDomain, theseWeights, sfcTemp, dLambda=1.0):
         raise McbratError("emission_weightingNEW: Neither surface nor atmosphere will emitt photons since "
                           "total power is 0. Not a valid solution")
     theseWeights.voxelWeights, theseWeights.fracAtmsPower, theseWeights.spectrIntgrFlux = vw, frac.value, flux.value
+    theseWeights._version += 1
     return flux.value
 
 

@@ -69,6 +69,8 @@ class Integrator:
         self._intensity_token = None
         self._domain_token = None
         self._source_token = None
+        self._loaded_domain = None   # strong references: what the device buffers were filled from
+        self._loaded_weights = None
         self._dims = None
         self._load_grid(atmosphere)
         self.readyToCompute = True
@@ -205,11 +207,11 @@ class Integrator:
         return int(self.intensityMus.size) if self.computeIntensity else 0
 
     def setTuning(self, blocksPerCU=-1, eventThreshold=0, maxBatchesInFlight=-1, privateTallies=-1, blockSize=-1,
-                  launchThreshold=0, surfaceThreshold=0, brickLayout=-1, layerSkip=-1, exchange=-1):
+                  launchThreshold=0, surfaceThreshold=0, brickLayout=-1, layerSkip=-1, blockWalk=-1):
         self._check(self._lib.mcbrat_set_tuning(self._ctx, blocksPerCU, eventThreshold, maxBatchesInFlight,
                                                 privateTallies, blockSize, launchThreshold, surfaceThreshold, brickLayout))
-        if layerSkip >= 0 or exchange >= 0:
-            self._check(self._lib.mcbrat_set_walk_options(self._ctx, int(layerSkip), int(exchange)))
+        if layerSkip >= 0 or blockWalk >= 0:
+            self._check(self._lib.mcbrat_set_walk_options(self._ctx, int(layerSkip), int(blockWalk)))
 
     def eventThreshold(self):
         return int(self._lib.mcbrat_get_event_threshold(self._ctx))
@@ -231,11 +233,14 @@ class Integrator:
 
     # -- computeRadiativeTransfer -------------------------------------------------------
     def _load_domain(self, dom):
-        token = (id(dom), id(dom.totalExt), self.minInverseTableSize, self.numIntensityDirections() > 0,
+        # What is on the device is remembered by CONTENT, never by object identity (CPython reuses the ids of freed
+        # objects): a strong reference to the domain, its version counter (addOpticalComponent and the albedo setter
+        # bump it) and the parameters the tables depend on.
+        info = dom.getInfo_Domain()  # (expands the component arrays if they are stale, before the token is formed)
+        token = (dom._version, self.minInverseTableSize, self.numIntensityDirections() > 0,
                  self.minForwardTableSize, self.useHybridPhaseFunsForIntenCalcs, self.hybridPhaseFunWidth)
-        if token == self._domain_token:
+        if dom is self._loaded_domain and token == self._domain_token:
             return
-        info = dom.getInfo_Domain()
         if (info["numX"], info["numY"], info["numZ"]) != self._dims:
             raise McbratError("computeRadiativeTransfer: domain does not match the integrator's grid")
         nc = info["numberOfComponents"]
@@ -256,11 +261,18 @@ class Integrator:
                 o = np.ascontiguousarray(o, np.float32)
                 self._check(self._lib.mcbrat_set_forward_table(self._ctx, c + 1, t.shape[1], t.shape[0], ptr(t),
                                                                ptr(o) if self.useHybridPhaseFunsForIntenCalcs else None))
+        self._loaded_domain = dom
         self._domain_token = token
         self._source_token = None
+        self._loaded_weights = None
 
     def _load_source(self, photons):
-        token = (id(photons), photons.kind)
+        if photons.kind == "Directional":  # the geometry itself is the token
+            token = ("Directional", float(photons.solarMu), float(photons.solarAzimuth))
+        else:  # strong reference to the weights + their version (emission_weighting bumps it)
+            token = ("BBEmission", photons.weights._version, float(photons.weights.fracAtmsPower))
+            if photons.weights is not self._loaded_weights:
+                self._source_token = None
         if token == self._source_token:
             return
         if photons.kind == "Directional":
@@ -269,6 +281,7 @@ class Integrator:
         else:
             self._check(self._lib.mcbrat_set_source_emission(self._ctx, ptr(photons.weights.voxelWeights),
                                                              photons.weights.fracAtmsPower))
+            self._loaded_weights = photons.weights
         self._source_token = token
 
     def computeRadiativeTransfer(self, thisDomain, randomNumbers, incomingPhotons, numPhotonsPerBatch, numBatches=1):

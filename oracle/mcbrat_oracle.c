@@ -309,6 +309,8 @@ static float surface_reflectance(const orc_problem *P, double xPos, double yPos)
   if (yi > nY - 1) yi = nY - 1;
   return P->surfReflectance[(size_t)(xi - 1) + (size_t)(nX - 1) * (yi - 1)];
 }
+/* exported for the pin against the reference's own computeSurfaceReflectance (tests/golden/ref_surface.json) */
+float orc_surface_reflectance(const orc_problem *P, double xPos, double yPos) { return surface_reflectance(P, xPos, yPos); }
 int orc_find_cdf_index(float vf, const double *t, int n) { /* :317-348 */
   double v = (double)vf;
   int lowerBound = 0, upperBound = n, midPoint;

@@ -108,6 +108,8 @@ def lib():
         L.orc_find_cdf_index.argtypes = [C.c_float, C.c_void_p, C.c_int]
         L.orc_emission_weighting.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_double] * 4 + [C.c_void_p] * 3
         L.orc_philox_init.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.orc_surface_reflectance.restype = C.c_float
+        L.orc_surface_reflectance.argtypes = [C.c_void_p, C.c_double, C.c_double]
         _LIB = L
     return _LIB
 
@@ -294,6 +296,10 @@ class Problem:
         self.surfR = np.ascontiguousarray(r.T).reshape(-1)  # x fastest
         self.c.surfNumX, self.c.surfNumY = self.surfX.size, self.surfY.size
         self.c.surfXPosition, self.c.surfYPosition, self.c.surfReflectance = _p(self.surfX), _p(self.surfY), _p(self.surfR)
+
+    def surface_reflectance(self, x, y):
+        """computeSurfaceReflectance(surfaceBDRF, xPos, yPos, ...), src/surfaceProperties.f95:119-147."""
+        return float(lib().orc_surface_reflectance(C.byref(self.c), float(x), float(y)))
 
     def grid_flags(self):
         a, b = C.c_int(), C.c_int()

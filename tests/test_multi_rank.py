@@ -35,6 +35,53 @@ def _moments_from_batches(P, src_args, first_batch, n_batches, nx, ny, nz):
     return buf
 
 
+class OracleIntegrator:
+    """Stands where each rank's GPU integrator does in driver.run (tests only): same calls, traced by the oracle in
+    Philox mode, batch moments accumulated into the bound buffer exactly as the finish kernels do."""
+
+    def __init__(self, P, src_args, dims, buf):
+        self.P, self.src_args, self._dims, self.buf, self.device = P, src_args, dims, buf, 0
+        self.synchronised = 0
+
+    def resetMoments(self):
+        self.buf[:] = 0.0
+
+    def synchronize(self):
+        self.synchronised += 1
+
+    def computeRadiativeTransfer(self, dom, rng, photons, ppb, nb):
+        first = rng.nextPhotonId // ppb
+        self.buf += _moments_from_batches(self.P, self.src_args, first, nb, *self._dims)
+        rng.nextPhotonId += ppb * nb
+        return ppb * nb
+
+    def moments(self):
+        return self.buf.copy()
+
+
+def _worker_driver_run(rank, world, port, out):
+    """driver.run itself over gloo: split, trace, all-reduce, statistics."""
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd.integrator import RandomNumberSequence
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = cases.oracle_problem(cases.step_cloud(0.99))
+    M_len = 3 + 3 * 32 + 32 + 32 * 32
+    t = torch.zeros(8 + 2 * M_len, dtype=torch.float64)
+    integ = OracleIntegrator(P, (1.0, 0.0), (32, 1, 32), t.numpy())
+    rng = RandomNumberSequence(SEED, 0)
+    photons = M.new_PhotonStream(1.0, 0.0, numberOfPhotons=PPB * NB)
+    stats = driver.run(integ, None, photons, PPB, NB, rng, dist=dist, moments_tensor=t)
+    assert integ.synchronised == 1  # (CPU tensors: the integrator is synchronised before the all-reduce)
+    assert rng.nextPhotonId == PPB * NB
+    if rank == 0:
+        np.save(out, np.concatenate([[stats["totalPhotons"], stats["batches"], stats["meanFluxUp"], stats["meanFluxDown"],
+                                      stats["meanFluxAbsorbed"], stats["meanFluxUp_StdErr"]], stats["absorbedProfile"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -67,6 +114,17 @@ def test_split_batches_covers_everything():
             for lo, n in parts:
                 assert lo == pos
                 pos += n
+
+
+def test_driver_run_over_two_gloo_ranks(tmp_path):
+    out = str(tmp_path / "stats.npy")
+    mp.spawn(_worker_driver_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    P = cases.oracle_problem(cases.step_cloud(0.99))
+    single = driver.statistics(driver.unpack_moments(_moments_from_batches(P, (1.0, 0.0), 0, NB, 32, 1, 32), 32, 1, 32))
+    want = np.concatenate([[single["totalPhotons"], single["batches"], single["meanFluxUp"], single["meanFluxDown"],
+                            single["meanFluxAbsorbed"], single["meanFluxUp_StdErr"]], single["absorbedProfile"]])
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-15)
 
 
 def test_two_rank_reduction_equals_single_rank(tmp_path):

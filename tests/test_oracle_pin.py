@@ -2,6 +2,8 @@
 
 1. utility layer: bit-for-bit against tests/golden/ref_numeric.json, which was
    produced by the reference's own numericUtilities.f95 (tests/golden/make_ref_numeric.py);
+   surface description: bit-for-bit against tests/golden/ref_surface.json, produced by the
+   reference's own surfaceProperties.f95 (tests/golden/make_ref_surface.py);
 2. MT19937: canonical known answers + the stream recorded in SURVEY.md section 8c;
 3. the whole photon loop: the reference's own outputs recorded in SURVEY.md
    section 8c / BASELINE.md section 2 (step cloud, seed (/10,1,0/), 1e5 and 1e6 photons),
@@ -55,6 +57,31 @@ def test_find_index_family(ref):
     cdf = np.array([0.05, 0.05, 0.2, 0.45, 0.450001, 0.8, 0.95, 1.0])
     for vb, i in ref["findcdf"]:
         assert O.find_cdf_index(f32([vb])[0], cdf) == i
+
+
+def test_surface_reflectance_bit_exact_against_the_reference():
+    """computeSurfaceReflectance / makePeriodic / findIndex of src/surfaceProperties.f95:119-147, :211-230: 2 x 600
+    positions (inside the surface, up to two periods outside it, exactly on the lower edge, on interior edges, a
+    hair past the upper edge) evaluated by the reference's own module (oracle/_ref/ref_surface, generator
+    tests/golden/make_ref_surface.py).  The oracle must return the same float, bit for bit; each patch carries a
+    reflectance that encodes its indices, so this pins the patch lookup, not just a value."""
+    with open(os.path.join(GOLD, "ref_surface.json")) as f:
+        gold = json.load(f)["surfaces"]
+    case = cases.step_cloud(0.99)
+    total = 0
+    for k, sfc in gold.items():
+        xs = np.array(sfc["xedge"], np.int64).view(np.float64)
+        ys = np.array(sfc["yedge"], np.int64).view(np.float64)
+        refl = np.array([[(i + 10 * j) for j in range(1, sfc["numY"])] for i in range(1, sfc["numX"])], np.float32) / np.float32(100.0)
+        P = cases.oracle_problem(dict(case, surface=(refl, xs, ys)))
+        pts = np.array(sfc["points"], np.int64)
+        x, y = pts[:, 0].view(np.float64), pts[:, 1].view(np.float64)
+        want = pts[:, 2].astype(np.int32)
+        got = np.array([P.surface_reflectance(a, b) for a, b in zip(x, y)], np.float32).view(np.int32)
+        assert np.array_equal(got, want), (k, np.nonzero(got != want)[0][:10])
+        assert len(set(want.tolist())) >= 0.75 * (sfc["numX"] - 1) * (sfc["numY"] - 1)  # (all but the narrowest patches were hit)
+        total += len(want)
+    assert total == 1200
 
 
 def test_mt19937_known_answers():
