@@ -207,6 +207,8 @@ int mcbrat_set_surface_description(mcbrat_ctx *ctx, int32_t numX, int32_t numY, 
  * from the position.  Same argument as for layerSkip: inside a block the reference's stops at cell faces only add
  * `segment x the same extinction` again.  0 restores the face-by-face walk. */
 int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t blockWalk);
+/* The walk options in force: bit 0 layerSkip, bit 1 blockWalk. */
+int mcbrat_get_walk_mode(const mcbrat_ctx *ctx);
 
 /* The event threshold in use (after the first call of a domain: the one chosen by the trial launches). */
 int mcbrat_get_event_threshold(const mcbrat_ctx *ctx);

@@ -1015,6 +1015,8 @@ int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip, int32_t blockWalk)
   return 0;
 }
 
+int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0)) : 0; }
+
 int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int64_t ppb, int32_t nBatches,
                                       int64_t *numPhotonsProcessed) {
   if (!c) return 1;

@@ -213,6 +213,10 @@ class Integrator:
         if layerSkip >= 0 or blockWalk >= 0:
             self._check(self._lib.mcbrat_set_walk_options(self._ctx, int(layerSkip), int(blockWalk)))
 
+    def walkMode(self):
+        m = int(self._lib.mcbrat_get_walk_mode(self._ctx))
+        return {"layerSkip": bool(m & 1), "blockWalk": bool(m & 2)}
+
     def eventThreshold(self):
         return int(self._lib.mcbrat_get_event_threshold(self._ctx))
 

@@ -27,11 +27,21 @@ def main():
     ap.add_argument("--brick", type=int, nargs="*", default=[-1])
     ap.add_argument("--block", type=int, nargs="*", default=[-1])
     ap.add_argument("--skip", type=int, nargs="*", default=[-1])
+    ap.add_argument("--bw", type=int, nargs="*", default=[-1], help="block walk (LDS-resident grids): -1 default, 0 off, 1 on")
+    ap.add_argument("--n", type=int, default=128, help="landsat / radar: columns per side")
+    ap.add_argument("--nz", type=int, default=64)
     a = ap.parse_args()
     import mcbrat3d_amd as M
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
-    case = cases.step_cloud(a.ssa) if a.case == "step" else (cases.radar_like() if a.case == "radar" else cases.landsat_like(ssa_cloud=a.ssa))
-    mu0, phi0 = (1.0, 0.0) if a.case == "step" else (0.5, 30.0)
+    if a.case == "step":
+        case = cases.step_cloud(a.ssa)
+    elif a.case == "plane":
+        case = cases.plane_parallel(ssa=a.ssa)
+    elif a.case == "radar":
+        case = cases.radar_like(n=a.n, nz=a.nz)
+    else:
+        case = cases.landsat_like(n=a.n, nz=a.nz, ssa_cloud=a.ssa)
+    mu0, phi0 = (1.0, 0.0) if a.case in ("step", "plane") else (0.5, 30.0)
     t0 = time.time()
     dom = cases.product_domain(case)
     integ = M.new_Integrator(dom)
@@ -39,10 +49,10 @@ def main():
     photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
     print("setup %.2fs" % (time.time() - t0), flush=True)
     import itertools
-    for bpc, priv, block, thr, lthr, sthr, brick, skip in itertools.product(a.bpc, a.priv, a.block, a.thr, a.lthr, a.sthr, a.brick, a.skip):
+    for bpc, priv, block, thr, lthr, sthr, brick, skip, bw in itertools.product(a.bpc, a.priv, a.block, a.thr, a.lthr, a.sthr, a.brick, a.skip, a.bw):
       for inflight in a.inflight:
         if True:
-            integ.setTuning(blocksPerCU=bpc, eventThreshold=thr, privateTallies=priv, blockSize=block, launchThreshold=lthr, surfaceThreshold=sthr, brickLayout=brick, maxBatchesInFlight=inflight, layerSkip=skip)
+            integ.setTuning(blocksPerCU=bpc, eventThreshold=thr, privateTallies=priv, blockSize=block, launchThreshold=lthr, surfaceThreshold=sthr, brickLayout=brick, maxBatchesInFlight=inflight, layerSkip=skip, blockWalk=bw)
             rates = []
             for r in range(a.reps):
                 rng = new_RandomNumberSequence(1234 + r)
@@ -58,8 +68,8 @@ def main():
                 print('   per photon: legs %.2f crossings %.2f collisions %.2f' % (c['legs'] / n, c['crossings'] / n, c['collisions'] / n))
                 print('   walk iters %.4g lanes/iter %.1f | event phases %.4g lanes/phase %.1f | launch phases %.4g surf phases %.4g | walk iters per event phase %.2f' % (c['walkIterations'], c['walkLanes']/max(1,c['walkIterations']), c['eventPhases'], c['eventLanes']/max(1,c['eventPhases']), c['launchPhases'], c['surfacePhases'], c['walkIterations']/max(1,c['eventPhases'])))
             res = integ.reportResults()
-            print("case=%s skip=%d bpc=%d priv=%d block=%d thr=%d lthr=%d sthr=%d brick=%d inflight=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
-                a.case, skip, bpc, priv, block, thr, lthr, sthr, brick, inflight, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
+            print("case=%s n=%d bw=%d skip=%d bpc=%d priv=%d block=%d thr=%d lthr=%d sthr=%d brick=%d inflight=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
+                a.case, a.n, bw, skip, bpc, priv, block, thr, lthr, sthr, brick, inflight, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
                 res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"]), flush=True)
 
 

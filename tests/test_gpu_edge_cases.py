@@ -264,3 +264,100 @@ def test_very_tall_grid(M):
     assert done == n
     for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
         assert abs(last[k] - ref[k]) < 3e-3, (k, last[k], ref[k])
+
+
+def test_one_integrator_reused_with_temporary_streams_and_changed_domains(M):
+    """The integrator remembers what is on the device by content, not by object identity: CPython hands the id of a
+    freed temporary to the next one, so three `new_PhotonStream(mu0, ...)` temporaries in a loop used to look like
+    one stream.  Same for a changed surface albedo and an added component."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.step_cloud(0.99)
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001)
+    n = 200000
+    downs = []
+    for mu0 in (1.0, 0.5, 0.25):
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(5), M.new_PhotonStream(mu0, 0.0, numberOfPhotons=n), n)
+        downs.append(integ.reportResults()["meanFluxDown"])
+    fresh = []
+    for mu0 in (1.0, 0.5, 0.25):
+        _, _, last, _ = _run(M, case, mu0, 0.0, n, 1, seed=5)
+        fresh.append(last["meanFluxDown"])
+    assert downs == fresh  # bitwise what a fresh integrator per sun angle gives
+    assert downs[0] > downs[1] > downs[2]
+    # a mutated stream object
+    ps = M.new_PhotonStream(1.0, 0.0, numberOfPhotons=10 * n)
+    integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(5), ps, n)
+    ps.solarMu = 0.25
+    integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(5), ps, n)
+    assert integ.reportResults()["meanFluxDown"] == fresh[2]
+    # the domain's albedo changed in place: photons now come back from the surface
+    up0 = integ.reportResults()["meanFluxUp"]
+    dom.surfaceAlbedo = 0.8
+    integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(5), ps, n)
+    assert integ.reportResults()["meanFluxUp"] > up0 + 0.1
+    integ.finalize()
+
+
+def test_one_context_reconfigured_through_the_abi(M):
+    """include/mcbrat.h allows set_grid / set_optics to be called again on a live context: buffers sized by the earlier
+    configuration (last-batch results, batch slabs whose stride grows with the number of components when
+    limitIntensityContributions is on) must be re-sized, not reused.  Small grid, then a larger one,
+    then one -> two components with clipped radiance contributions; each against a fresh context, bitwise."""
+    import ctypes as C
+    from mcbrat3d_amd._capi import check, lib, ptr
+    from oracle import oracle as O  # (only to expand the components into the arrays the ABI takes)
+    L = lib()
+
+    def configure(ctx, case, inten, regrid=True):
+        nx, ny, nz = len(case["xe"]) - 1, len(case["ye"]) - 1, len(case["ze"]) - 1
+        tot, cum, ssa, pfi = O.optical_properties_by_component(nx, ny, nz, case["components"])
+        if regrid:
+            check(ctx, L.mcbrat_set_grid(ctx, nx, ny, nz, ptr(np.ascontiguousarray(case["xe"], np.float64)),
+                                         ptr(np.ascontiguousarray(case["ye"], np.float64)), ptr(np.ascontiguousarray(case["ze"], np.float64))))
+        nc = len(case["components"])
+        check(ctx, L.mcbrat_set_optics(ctx, nc, ptr(tot), ptr(cum), ptr(ssa), ptr(pfi), C.c_double(case["albedo"])))
+        dom = cases.product_domain(case)
+        for c, t in enumerate(dom.tabulateInversePhaseFunctions(9001)):
+            t = np.ascontiguousarray(t, np.float32)
+            check(ctx, L.mcbrat_set_inverse_table(ctx, c + 1, t.shape[1], t.shape[0], ptr(t)))
+        mus, phis = np.array([1.0, 0.6], np.float32), np.array([0.0, 40.0], np.float32)
+        if inten:
+            tab, _ = dom.tabulateForwardPhaseFunctions(9001)
+            check(ctx, L.mcbrat_specify_intensity(ctx, 2, ptr(mus), ptr(phis), 0, C.c_float(0.3), 0, 0, 1, C.c_float(0.05)))
+            for c, t in enumerate(tab):
+                t = np.ascontiguousarray(t, np.float32)
+                check(ctx, L.mcbrat_set_forward_table(ctx, c + 1, t.shape[1], t.shape[0], ptr(t), None))
+        else:
+            check(ctx, L.mcbrat_specify_intensity(ctx, 0, None, None, 0, C.c_float(0.3), 0, 0, 0, C.c_float(1e30)))
+        check(ctx, L.mcbrat_specify_parameters(ctx, 1, 1, C.c_float(-1.0)))
+        check(ctx, L.mcbrat_set_source_solar(ctx, C.c_float(0.7), C.c_float(20.0)))
+        return nx * ny, nz
+
+    def trace(ctx):
+        done = C.c_int64(0)
+        check(ctx, L.mcbrat_reset_moments(ctx))
+        check(ctx, L.mcbrat_compute_radiative_transfer(ctx, 9, 0, 3000, 7, C.byref(done)))
+        buf = np.zeros(8 + 2 * int(L.mcbrat_moments_length(ctx)), np.float64)
+        check(ctx, L.mcbrat_get_moments(ctx, ptr(buf)))
+        return buf
+
+    small = cases.plane_parallel(ssa=0.9)
+    big = cases.stretched_grid_cloud()
+    one = cases.landsat_like(n=12, nz=10, rayleigh=False)
+    two = cases.landsat_like(n=12, nz=10, rayleigh=True)
+    steps = [(small, False), (big, False), (one, True), (two, True), (small, False)]
+    ctx = L.mcbrat_create(0)
+    assert ctx
+    reused = []
+    for i, (case, inten) in enumerate(steps):
+        configure(ctx, case, inten, regrid=(i != 3))  # one -> two components on the SAME grid: set_optics alone
+        reused.append(trace(ctx))
+    L.mcbrat_destroy(ctx)
+    for (case, inten), got in zip(steps, reused):
+        fresh = L.mcbrat_create(0)
+        configure(fresh, case, inten)
+        want = trace(fresh)
+        L.mcbrat_destroy(fresh)
+        assert got.shape == want.shape and np.array_equal(got, want), case["name"]
