@@ -124,8 +124,8 @@ def z_scores(g, ge, r, re):
 def parity_block(stats, batches, cols, prof, ccnt, ctot):
     """z = (GPU - REF) / sqrt(sigma_GPU^2 + sigma_REF^2), sigma from the batch variance
     (the driver's estimator, monteCarloDriver.f95:1188-1219), over the domain means, every column flux and every
-    level of the absorption (heating) profile; pass = max |z| < 4 over the bins (5 beyond 10^4 bins: the largest
-    of N unit normals grows like sqrt(2 ln N)) and |mean z| < 0.2."""
+    level of the absorption (heating) profile; pass = max |z| < max(4, sqrt(2 ln N) + 1) over N bins (the largest of N
+    unit normals grows like sqrt(2 ln N)) and |mean z| < 0.2."""
     from oracle import oracle as O
     m_ref, e_ref = O.batch_statistics(batches)
     c_ref, ce_ref = O.batch_statistics(cols)
@@ -138,7 +138,7 @@ def parity_block(stats, batches, cols, prof, ccnt, ctot):
     zc = z_scores(gc, gce, c_ref, ce_ref)
     live = (np.asarray(stats["absorbedProfile_StdErr"]) > 0) | (pe_ref > 0)  # (levels nothing is absorbed in carry no statistic)
     zp = z_scores(stats["absorbedProfile"], stats["absorbedProfile_StdErr"], p_ref, pe_ref)[live]
-    lim_c = 4.0 if zc.size <= 10000 else 5.0
+    lim_c = max(4.0, float(np.sqrt(2.0 * np.log(max(zc.size, 2))) + 1.0))
     ok = bool(np.max(np.abs(zc)) < lim_c and abs(np.mean(zc)) < 0.2 and (zp.size == 0 or np.max(np.abs(zp)) < 4.0)
               and np.max(np.abs(z)) < 4.0)
     return {"gpu_photons": int(stats["totalPhotons"]), "cpu_photons": int(ctot),

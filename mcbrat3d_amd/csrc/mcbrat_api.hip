@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "mcbrat_kernels.hip"
+#include "mcbrat_blockwalk.hip"
 
 using namespace mcbrat;
 
@@ -58,6 +59,11 @@ struct mcbrat_ctx {
   float *dLayerExt = nullptr;  // [nz] extinction of a horizontally uniform layer, -1 otherwise
   int *dLayerRun = nullptr;    // [nz] runs of such layers (DevParams::layerRun)
   double *dLayerRunT = nullptr;  // [nz+1]
+  // block walk (mcbrat_blockwalk.hip)
+  uint32_t *dBlockRec = nullptr;
+  uint16_t *dBlockOf = nullptr;
+  int nBlocks = 0;
+  int crossThreshold = 8;      // MCBRAT_CROSS_THRESHOLD
   float *dExtB = nullptr, *dCumB = nullptr, *dSsaB = nullptr, *dBgExt = nullptr, *dBgCum = nullptr, *dBgSsa = nullptr;
   uint16_t *dPfiB = nullptr, *dBgPfi = nullptr;
   int nbx = 0, nby = 0, nbz = 0;
@@ -340,6 +346,57 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
   return 0;
 }
 
+// Block walk (mcbrat_blockwalk.hip): cuts the grid into axis-aligned blocks of cells that carry one extinction value.
+// Greedy: the first cell without a block (x fastest) grows along x, then the row grows along y, then the slab along z,
+// as long as every new cell has the same extinction and no block yet.  Any partition into such blocks is valid; this
+// one finds the two slabs of the I3RC step cloud, the one slab of a plane-parallel medium and the clear air around clouds.
+int build_blocks(mcbrat_ctx *c, const std::vector<float> &e) {
+  const int nx = c->nx, ny = c->ny, nz = c->nz;
+  const size_t nvox = (size_t)nx * ny * nz;
+  c->nBlocks = 0;
+  if (c->dBlockRec) { (void)hipFree(c->dBlockRec); c->dBlockRec = nullptr; }
+  if (c->dBlockOf) { (void)hipFree(c->dBlockOf); c->dBlockOf = nullptr; }
+  // only grids that can live in LDS are walked this way (plan_launch decides); bounds are packed in 16 bits
+  if (nvox > 65536 || nx > 65535 || ny > 65535 || nz > 65535) return 0;
+  std::vector<int> of(nvox, -1);
+  std::vector<uint32_t> rec;
+  auto at = [&](int i, int j, int k) { return (size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k); };
+  for (int k = 0; k < nz; ++k)
+    for (int j = 0; j < ny; ++j)
+      for (int i = 0; i < nx; ++i) {
+        if (of[at(i, j, k)] >= 0) continue;
+        const float v = e[at(i, j, k)];
+        int x1 = i + 1, y1 = j + 1, z1 = k + 1;
+        while (x1 < nx && of[at(x1, j, k)] < 0 && e[at(x1, j, k)] == v) ++x1;
+        for (; y1 < ny; ++y1) {
+          bool ok = true;
+          for (int ii = i; ii < x1 && ok; ++ii) ok = of[at(ii, y1, k)] < 0 && e[at(ii, y1, k)] == v;
+          if (!ok) break;
+        }
+        for (; z1 < nz; ++z1) {
+          bool ok = true;
+          for (int jj = j; jj < y1 && ok; ++jj)
+            for (int ii = i; ii < x1 && ok; ++ii) ok = of[at(ii, jj, z1)] < 0 && e[at(ii, jj, z1)] == v;
+          if (!ok) break;
+        }
+        const int id = (int)(rec.size() / 4);
+        for (int kk = k; kk < z1; ++kk)
+          for (int jj = j; jj < y1; ++jj)
+            for (int ii = i; ii < x1; ++ii) of[at(ii, jj, kk)] = id;
+        rec.push_back((uint32_t)i | ((uint32_t)x1 << 16));
+        rec.push_back((uint32_t)j | ((uint32_t)y1 << 16));
+        rec.push_back((uint32_t)k | ((uint32_t)z1 << 16));
+        rec.push_back((i == 0 && x1 == nx ? 1u : 0u) | (j == 0 && y1 == ny ? 2u : 0u));
+      }
+  const size_t nb = rec.size() / 4;
+  if (nb > 65535) return 0;
+  std::vector<uint16_t> of16(nvox);
+  for (size_t v = 0; v < nvox; ++v) of16[v] = (uint16_t)of[v];
+  if (upload(c, &c->dBlockRec, rec.data(), rec.size()) || upload(c, &c->dBlockOf, of16.data(), of16.size())) return 1;
+  c->nBlocks = (int)nb;
+  return 0;
+}
+
 // Bricks are for grids that no longer fit the cache hierarchy (32 MiB of L2 + 256 MiB Infinity
 // Cache) and are mostly background.  Measured on MI355X: at 128x128x64 (4 MiB of extinction) the
 // dense grid is as fast or 1-3 % faster, so the automatic rule only switches
@@ -406,6 +463,8 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   for (int k = 0; k < c->nc && c->nDir > 0; ++k) { p.fwdOffset[k] = c->fwdOffset[k]; p.fwdNAngles[k] = c->fwdNAngles[k]; }
   p.useHybrid = c->useHybrid; p.numOrdersOrig = c->numOrdersOrig; p.useRRIntensity = c->useRRIntensity; p.zetaMin = c->zetaMin;
   p.limitContrib = c->limitContrib; p.maxContrib = c->maxContrib;
+  p.nBlocks = c->nBlocks; p.blockRec = reinterpret_cast<const uint4 *>(c->dBlockRec); p.blockOf = c->dBlockOf;
+  p.crossThreshold = std::max(1, std::min(64, c->crossThreshold));
   p.counter = c->L().dCounter;
   p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
   p.launchThreshold = std::max(1, std::min(64, c->launchThreshold));
@@ -514,6 +573,47 @@ int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatche
                   : launch_trace_t<BLOCK, false, 0, false, DBG>(c, p, L.lds, nBatches);
 }
 
+// The block walk applies where the face-by-face plan already keeps grid, tallies (and tables) in LDS, radiance is off,
+// and blocks are worth it: at least four cells per block on average (a medium that differs from cell to cell would
+// pay a position look-up at every face for nothing).
+bool block_walk_applies(const mcbrat_ctx *c, const LaunchPlan &L) {
+  if (!c->blockWalk || !(L.priv && L.gridLds) || c->nDir > 0 || c->nBlocks <= 0) return false;
+  const size_t nvox = (size_t)c->nx * c->ny * c->nz;
+  return (size_t)c->nBlocks * 4 <= nvox || c->blockWalk == 2;  // (2: forced, for tests of heterogeneous media)
+}
+
+template <int BLOCK, bool TBL, bool DBG>
+int launch_block_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
+  auto kernel = trace_block_kernel<BLOCK, TBL, DBG>;
+  if (lds > c->ldsPerCU) return fail(c, "computeRadiativeTransfer: the block-walk tables do not fit the LDS of a compute unit.");
+  if (lds > kLdsBudget)
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int perCU = c->blocksPerCU;
+  if (perCU <= 0) {
+    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, BLOCK, lds));
+    perCU = std::max(1, std::min(perCU, 8));
+  }
+  unsigned long long blocks = (unsigned long long)perCU * c->numCUs;
+  unsigned long long upb = std::max<unsigned long long>(1, blocks / (unsigned long long)nBatches);
+  upb = std::min<unsigned long long>(upb, std::max<unsigned long long>(1, p.ppb / (unsigned long long)(BLOCK * 8)));
+  p.unitsPerBatch = upb;
+  p.nUnits = upb * (unsigned long long)nBatches;
+  blocks = std::min(blocks, p.nUnits);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<unsigned long long>(1, blocks)), dim3(BLOCK), lds, c->L().stream, p);
+  HIP_OK(c, hipGetLastError());
+  return 0;
+}
+
+int launch_block(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, bool debug, int nBatches) {
+  const size_t lds = block_lds_layout(c->nx, c->ny, c->nz, c->nc, (size_t)p.slabStride, c->nBlocks,
+                                      L.tblLds ? (size_t)c->tblTotalFloats : 0).total;
+  const int block = c->blockSize > 0 ? c->blockSize : 768;
+  if (debug) return L.tblLds ? launch_block_t<512, true, true>(c, p, lds, nBatches) : launch_block_t<512, false, true>(c, p, lds, nBatches);
+  if (block == 768) return L.tblLds ? launch_block_t<768, true, false>(c, p, lds, nBatches) : launch_block_t<768, false, false>(c, p, lds, nBatches);
+  if (block == 256) return L.tblLds ? launch_block_t<256, true, false>(c, p, lds, nBatches) : launch_block_t<256, false, false>(c, p, lds, nBatches);
+  return L.tblLds ? launch_block_t<512, true, false>(c, p, lds, nBatches) : launch_block_t<512, false, false>(c, p, lds, nBatches);
+}
+
 int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   LaunchPlan L = plan_launch(c, (size_t)p.slabStride);
   if (L.priv && L.brick) {  // fill_params chose the brick arrays: private tallies give way
@@ -521,6 +621,7 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
     L.gridLds = false;
     L.lds = plan_launch_lds(c, L);
   }
+  if (block_walk_applies(c, L)) return launch_block(c, p, L, debug, nBatches);
   // small domains (grid, tables and tallies in LDS): LDS holds two workgroups per CU, and two workgroups of 12 waves
   // (6 per SIMD, 80 VGPRs) beat two of 8 (4 per SIMD, no spills) by 10 % on the step cloud (640 and 896 lanes lose)
   // (radiance on LDS-resident domains keeps 512 lanes: 768 lanes at 80 VGPRs lose 20 % there)
@@ -593,6 +694,7 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (const char *e = getenv("MCBRAT_REGULAR_WALK")) c->regularWalk = atoi(e);
   if (const char *e = getenv("MCBRAT_LAYER_SKIP")) c->layerSkip = atoi(e);
   if (const char *e = getenv("MCBRAT_BLOCK_WALK")) c->blockWalk = atoi(e);
+  if (const char *e = getenv("MCBRAT_CROSS_THRESHOLD")) c->crossThreshold = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_RAY_DEFER")) c->rayDefer = atoi(e);
   if (const char *e = getenv("MCBRAT_RAY_SHORT")) c->rayShort = std::max(1, atoi(e));
   if (const char *e = getenv("MCBRAT_RAY_PASS_ITERS")) c->rayPassIters = std::max(1, atoi(e));
@@ -617,7 +719,7 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   (void)sync_all(c);
   void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF,
                   c->dEventCounters, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
-                  c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dSurfX, c->dSurfY, c->dSurfRefl};
+                  c->dBlockRec, c->dBlockOf, c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dSurfX, c->dSurfY, c->dSurfRefl};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (mcbrat_ctx::Lane &L : c->lane) {
     void *lb[] = {L.dCounter, L.dSlabs, L.dColVals, L.dScalVals};
@@ -722,6 +824,7 @@ int mcbrat_set_optics(mcbrat_ctx *c, int32_t nc, const double *totalExt, const d
   }
   c->bricksBuilt = false;
   if (build_bricks(c, e, cu, s, pf, nc)) return 1;
+  if (build_blocks(c, e)) return 1;
   c->nc = nc;
   c->albedo = (float)albedo;
   c->maxPfi = maxPfi;
@@ -1011,7 +1114,7 @@ int mcbrat_set_surface_description(mcbrat_ctx *c, int32_t numX, int32_t numY, co
 int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip, int32_t blockWalk) {
   if (!c) return 1;
   if (layerSkip >= 0) { if ((layerSkip != 0) != (c->layerSkip != 0)) c->tuned = false; c->layerSkip = layerSkip ? 1 : 0; }
-  if (blockWalk >= 0) { if ((blockWalk != 0) != (c->blockWalk != 0)) c->tuned = false; c->blockWalk = blockWalk ? 1 : 0; }
+  if (blockWalk >= 0) { if (blockWalk != c->blockWalk) c->tuned = false; c->blockWalk = std::min(blockWalk, 2); }
   return 0;
 }
 

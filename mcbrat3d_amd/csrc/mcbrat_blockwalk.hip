@@ -1,0 +1,550 @@
+// mcbrat_blockwalk.hip -- the photon loop for domains whose optical grid is resident in LDS, walking from BLOCK
+// face to block face.
+//
+// What is replaced: the same computeRT loop as mcbrat_kernels.hip (Integrators/monteCarloRadiativeTransfer.f95:393-841,
+// accumulateExtinctionAlongPath src/opticalProperties.f95:1656-1815).  The reference's walk stops at every cell face
+// to add `segment x extinction of the cell` (:1743).  Where neighbouring cells carry the SAME extinction those stops
+// add the same product in pieces: the I3RC step cloud is two homogeneous slabs side by side, a plane-parallel
+// medium is one, and a leg of either crosses 3-4 cell faces on average before it collides.  Here the host cuts the
+// grid into axis-aligned blocks of cells with one extinction value (mcbrat_api.hip: build_blocks) and a leg goes from
+// block face to block face; the cell of a collision (tallies, single-scattering albedo, phase function entry) and
+// the column of an exit come from the POSITION.  Same physics, the optical depth of a leg summed per block instead
+// of per cell (float rounding, as with the layer-skipping walk of the large-domain kernel).
+//
+// Why it is a kernel of its own and not an option of trace_kernel: with 3-4 cell faces per leg trace_kernel
+// alternates between a walk loop and an event phase, each at about half lane occupancy.  With blocks nearly every
+// leg of the step cloud ends in the block it starts in, so there is no walk loop left: ONE loop in which every
+// lane that has a collision pending is served each iteration (collision -> new direction -> next leg's free path
+// -> distance to the block faces -> collide again or not), and the rare kinds of work -- launches, surface
+// reflections, block crossings -- wait until enough lanes have queued up, as launches and reflections already did.
+//
+// Shared with mcbrat_kernels.hip: Philox slots (same table: the oracle's Philox mode replays these photons), fixed
+// point tallies, private LDS tally slab per workgroup unit, launch / surface / scattering arithmetic (bit for bit).
+#include <float.h>
+
+#include "mcbrat_device.h"
+
+namespace mcbrat {
+
+// lane states of this kernel
+enum : int { BW_DEAD = 0, BW_MOVE = 1, BW_COLLIDE = 2, BW_SURFACE = 3, BW_TOP = 4, BW_CROSS = 5 };
+
+// 0-based layer of height z (no periodicity in z): by division where the reference calls z regular, bisection otherwise
+__device__ __forceinline__ int locate_z(const double *ze, int nz, bool regular, double z0, double invDz, double z) {
+  if (!regular) return find_cell(ze, nz, z);
+  return min(max((int)((z - z0) * invDz), 0), nz - 1);  // the reference's own map on a regular axis (findZIndex :1580-1592)
+}
+
+// DEBUG: cell index along a periodic axis counted through the periodic images (faces crossed = |difference|)
+__device__ __forceinline__ long long unwrapped_index(const double *e, int n, double x0, double L, double invL, double x) {
+  const double k = floor((x - x0) * invL);
+  return (long long)k * n + find_cell(e, n, x - k * L);
+}
+
+// LDS layout of trace_block_kernel (byte offsets), computed the same way by the host (plan_launch) and the kernel
+struct BlockLds {
+  size_t slab, cursor, rec, ext, ssa, cum, pfi, blockOf, tbl, total;
+};
+__host__ __device__ inline BlockLds block_lds_layout(int nx, int ny, int nz, int nc, size_t slabLen, int nBlocks, size_t tblFloats) {
+  BlockLds L;
+  const size_t nvox = (size_t)nx * ny * nz;
+  size_t o = sizeof(double) * (size_t)(nx + ny + nz + 3);
+  L.slab = o; o += sizeof(long long) * slabLen;
+  L.cursor = o; o += 16;
+  o = (o + 15) & ~(size_t)15;
+  L.rec = o; o += 16 * (size_t)nBlocks;
+  L.ext = o; o += 4 * nvox;
+  L.ssa = o; o += 4 * nvox * nc;
+  L.cum = o; o += nc > 1 ? 4 * nvox * nc : 0;  // (read only when there is more than one component)
+  L.pfi = o; o += 2 * ((nvox * nc + 1) & ~(size_t)1);
+  L.blockOf = o; o += 2 * ((nvox + 1) & ~(size_t)1);
+  L.tbl = o; o += 4 * tblFloats;
+  L.total = o;
+  return L;
+}
+
+template <int BLOCK, bool TBL_LDS, bool DEBUG>
+__global__ void __launch_bounds__(BLOCK, BLOCK > 512 ? BLOCK / 128 : MCBRAT_MIN_WAVES_PER_SIMD)
+trace_block_kernel(const DevParams p) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  // LDS map: [edges x|y|z (double)] [private tally slab (i64)] [unit cursor] [block records (uint4)] [extinction]
+  //          [ssa] [cum] [phase index (u16)] [block of each cell (u16)] [tables (float), TBL_LDS]
+  double *s_edge = reinterpret_cast<double *>(smem_raw);
+  const int nEdges = p.nx + p.ny + p.nz + 3;
+  const int ncol = p.nx * p.ny;
+  const int nvox = ncol * p.nz;
+  const int slabLen = (int)p.slabStride;
+  const BlockLds lay = block_lds_layout(p.nx, p.ny, p.nz, p.nc, (size_t)slabLen, p.nBlocks, TBL_LDS ? (size_t)p.tblTotalFloats : 0);
+  long long *s_slab = reinterpret_cast<long long *>(smem_raw + lay.slab);
+  unsigned *s_cursor = reinterpret_cast<unsigned *>(smem_raw + lay.cursor);
+  uint4 *s_blockRec = reinterpret_cast<uint4 *>(smem_raw + lay.rec);
+  float *s_ext = reinterpret_cast<float *>(smem_raw + lay.ext);
+  float *s_ssa = reinterpret_cast<float *>(smem_raw + lay.ssa);         // [nc][nvox]
+  float *s_cum = reinterpret_cast<float *>(smem_raw + lay.cum);         // [nc][nvox]
+  uint16_t *s_pfi = reinterpret_cast<uint16_t *>(smem_raw + lay.pfi);   // [nc][nvox]
+  uint16_t *s_blockOf = reinterpret_cast<uint16_t *>(smem_raw + lay.blockOf);  // [nvox]
+  float *s_tbl = reinterpret_cast<float *>(smem_raw + lay.tbl);
+  __shared__ int s_tblOffset[MCBRAT_MAX_COMPONENTS], s_tblNSteps[MCBRAT_MAX_COMPONENTS];
+  __shared__ float s_tblInvN[MCBRAT_MAX_COMPONENTS];
+  if (threadIdx.x < MCBRAT_MAX_COMPONENTS) {
+    s_tblOffset[threadIdx.x] = p.tblOffset[threadIdx.x];
+    s_tblNSteps[threadIdx.x] = p.tblNSteps[threadIdx.x];
+    s_tblInvN[threadIdx.x] = p.tblInvN[threadIdx.x];
+  }
+  for (int i = threadIdx.x; i < nEdges; i += BLOCK) s_edge[i] = p.edges[i];
+  if (TBL_LDS)
+    for (int i = threadIdx.x; i < p.tblTotalFloats; i += BLOCK) s_tbl[i] = p.tables[i];
+  for (int i = threadIdx.x; i < slabLen; i += BLOCK) s_slab[i] = 0;
+  if (threadIdx.x == 0) s_cursor[0] = 0;
+  for (int i = threadIdx.x; i < p.nBlocks; i += BLOCK) s_blockRec[i] = p.blockRec[i];
+  for (int i = threadIdx.x; i < nvox; i += BLOCK) { s_ext[i] = p.ext[i]; s_blockOf[i] = p.blockOf[i]; }
+  for (int i = threadIdx.x; i < p.nc * nvox; i += BLOCK) { s_ssa[i] = p.ssa[i]; s_pfi[i] = p.pfi[i]; }
+  if (p.nc > 1)
+    for (int i = threadIdx.x; i < p.nc * nvox; i += BLOCK) s_cum[i] = p.cum[i];
+  __syncthreads();
+  const float *__restrict__ tbl = TBL_LDS ? s_tbl : p.tables;
+  const int offY = p.nx + 1, offZ = p.nx + p.ny + 2;  // edge table offsets
+  const double invDz = (double)p.nz / (p.zMax - p.z0);
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned long long laneBelow = (1ull << lane) - 1ull;
+
+  // this workgroup's unit = photons [unitFirst, unitFirst + unitCount) of ONE batch
+  unsigned long long unitFirst = 0;
+  unsigned unitCount = 0;
+  long long *unitSlab = nullptr;
+
+  // lane state --------------------------------------------------------------------------
+  int state = BW_DEAD;
+  bool more = true;
+  uint32_t idLo = 0, idHi = 0, event = 0;
+  double px = 0, py = 0, pz = 0;      // leg origin (in the periodic image the leg is currently in)
+  float dx = 0, dy = 0, dz = 1;       // direction cosines
+  float ivx = 0, ivy = 0, ivz = 0;    // 1/direction
+  float tnx = 0, tny = 0, tnz = 0, tcur = 0;  // distance along the leg to the x/y/z face of the current BLOCK
+  float acc = 0, tau = 0, w = 0, extCur = 0, uX = 0, uY = 0, uZ = 0;
+  int fz = 0;                          // z face (0..nz) of the current block ahead of the lane
+  int fx = 0, fy = 0;                  // x / y faces ahead (0..nx, 0..ny)
+  unsigned spans = 0;                  // bit 0 / 1: the current block spans the whole periodic x / y axis
+  int nScat = 0, nLegs = 0;
+  long long dbgX = 0, dbgY = 0;        // DEBUG: cell of the leg's start counted through the periodic images
+  int dbgZ = 0;
+  unsigned int cLegs = 0, cCross = 0, cColl = 0, cAbs = 0, cTop = 0, cSurf = 0, cKill = 0, cSurv = 0;
+  unsigned long long wIters = 0, wCrossPhases = 0, wCrossLanes = 0, wEventLanes = 0, wLaunchPhases = 0, wSurfPhases = 0;
+
+  // faces crossed by the leg that ends at (x, y) / layer index kz (DEBUG: the reference's crossing count)
+  auto countCrossings = [&](double x, double y, int kzEnd) {
+    const long long ex = unwrapped_index(s_edge, p.nx, p.x0, p.Lx, p.invLx, x);
+    const long long ey = unwrapped_index(s_edge + offY, p.ny, p.y0, p.Ly, p.invLy, y);
+    cCross += (unsigned)(llabs(ex - dbgX) + llabs(ey - dbgY) + abs(kzEnd - dbgZ));
+  };
+
+  // Cell of position xw / yw on a periodic axis; folds the leg origin into the image that position lies in (DEBUG:
+  // the leg's start index follows the origin through the images, so that index differences stay face counts).
+  // `canLeave`: the position may lie outside the principal image (the lane comes out of a block that spans the whole
+  // axis); otherwise it is inside the domain and no fold is needed.  On axes the reference itself calls equally
+  // spaced the cell is its own formula, int((x - x0) / delta) (findXYIndicies :1558-1562); else the edge table decides.
+  auto locX = [&](double xw, bool canLeave, bool force = false) {
+    if (p.nx == 1 && !force) return 0;  // (one column: nothing to find; the origin is folded where the position itself is used)
+    if (canLeave) {
+      const double shift = floor((xw - p.x0) * p.invLx) * p.Lx;
+      px -= shift; xw -= shift;
+      if (DEBUG) dbgX -= (long long)rint(shift * p.invLx) * p.nx;
+    }
+    if (p.xyRegular) return min(max((int)((xw - p.x0) * p.invDX), 0), p.nx - 1);
+    double o = 0.0;
+    return locate_periodic(s_edge, p.nx, p.x0, p.Lx, p.invLx, p.invCellX, p.xyNearUniform != 0, o, xw);
+  };
+  auto locY = [&](double yw, bool canLeave, bool force = false) {
+    if (p.ny == 1 && !force) return 0;
+    if (canLeave) {
+      const double shift = floor((yw - p.y0) * p.invLy) * p.Ly;
+      py -= shift; yw -= shift;
+      if (DEBUG) dbgY -= (long long)rint(shift * p.invLy) * p.ny;
+    }
+    if (p.xyRegular) return min(max((int)((yw - p.y0) * p.invDY), 0), p.ny - 1);
+    double o = 0.0;
+    return locate_periodic(s_edge + offY, p.ny, p.y0, p.Ly, p.invLy, p.invCellY, p.xyNearUniform != 0, o, yw);
+  };
+  // Distances along the leg to the faces of the block that holds cell (ix, iy, iz); its extinction.
+  auto enterBlock = [&](int ix, int iy, int iz) {
+    const int cell = ix + p.nx * (iy + p.ny * iz);
+    const uint4 rec = s_blockRec[s_blockOf[cell]];
+    extCur = s_ext[cell];
+    fx = dx >= 0.0f ? (int)(rec.x >> 16) : (int)(rec.x & 0xffffu);
+    fy = dy >= 0.0f ? (int)(rec.y >> 16) : (int)(rec.y & 0xffffu);
+    fz = dz >= 0.0f ? (int)(rec.z >> 16) : (int)(rec.z & 0xffffu);
+    // a block that spans a whole periodic axis has no face on it (the lane's position runs through the images)
+    spans |= rec.w;  // (a leg that has been through such a block may have left the principal image since its last fold)
+    tnx = ((rec.w & 1u) || ivx == 0.0f) ? FLT_MAX : (float)(s_edge[fx] - px) * ivx;
+    tny = ((rec.w & 2u) || ivy == 0.0f) ? FLT_MAX : (float)(s_edge[offY + fy] - py) * ivy;
+    tnz = ivz == 0.0f ? FLT_MAX : (float)(s_edge[offZ + fz] - pz) * ivz;
+  };
+
+  for (unsigned long long unit = blockIdx.x;; unit += gridDim.x) {
+    if (unit >= p.nUnits) break;  // workgroup-uniform
+    uint32_t batch;
+    {
+      const unsigned long long b = unit / p.unitsPerBatch, s = unit % p.unitsPerBatch;
+      const unsigned long long bp = (p.total - b * p.ppb) < p.ppb ? (p.total - b * p.ppb) : p.ppb;
+      const unsigned long long lo = (bp * s) / p.unitsPerBatch, hi = (bp * (s + 1)) / p.unitsPerBatch;
+      unitFirst = b * p.ppb + lo;
+      unitCount = (unsigned)(hi - lo);
+      unitSlab = p.slabs + b * p.slabStride;
+      batch = (uint32_t)b;
+      more = true;
+    }
+    (void)batch;
+
+    for (;;) {
+      bool needLeg = false;
+      int ix = 0, iy = 0, iz = 0;  // cell of a lane that starts a leg in this iteration
+      // Rare kinds of work wait until enough lanes ask for them -- or until the wave has little else to do.
+      const unsigned long long mDead = __ballot(state == BW_DEAD && more);
+      const unsigned long long mSurf = __ballot(state == BW_SURFACE);
+      const unsigned long long mCross = __ballot(state == BW_CROSS);
+      const int nBusy = __popcll(__ballot(state == BW_COLLIDE || state == BW_TOP));
+      const bool idle = nBusy < p.eventThreshold;
+      const bool doLaunch = __popcll(mDead) >= p.launchThreshold || idle;
+      const bool doSurface = __popcll(mSurf) >= p.surfaceThreshold || idle;
+      const bool doCross = __popcll(mCross) >= p.crossThreshold || idle;
+      const unsigned long long want = doLaunch ? mDead : 0ull;
+      if (DEBUG) {
+        wIters++;
+        wEventLanes += nBusy;
+        if (want) wLaunchPhases++;
+        if (doSurface && mSurf) wSurfPhases++;
+        if (doCross && mCross) { wCrossPhases++; wCrossLanes += __popcll(mCross); }
+      }
+      if (want != 0ull) {  // wave-uniform
+        const int nWant = __popcll(want);
+        const int rank = __popcll(want & laneBelow);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&s_cursor[0], (unsigned)nWant);
+        base = (unsigned)__shfl((int)base, 0);
+        const unsigned k = base + (unsigned)rank;
+        const bool valid = k < unitCount;
+        const unsigned long long myIdx = unitFirst + k;
+        if (state == BW_DEAD && more) {
+          if (valid) {
+            // ---- launch: getNextPhoton + computeRT :466-508 (as in trace_kernel, bit for bit) ----
+            const unsigned long long id = p.firstPhoton + myIdx;
+            idLo = (uint32_t)id; idHi = (uint32_t)(id >> 32);
+            event = 0; nScat = 0; nLegs = 0;
+            uint32_t r[4];
+            philox4x32_10(0u, 0u, idLo, idHi, p.seedLo, p.seedHi, r);
+            double lx, ly, lz;  // fractional launch position in [0,1]
+            if (p.srcKind == 0) {  // newPhotonStream_Directional, monteCarloIllumination.f95:88-96
+              lx = (double)u01(r[0]);
+              ly = (double)u01(r[1]);
+              lz = 0.0;
+              dx = p.dir0[0]; dy = p.dir0[1]; dz = p.dir0[2];
+            } else {  // newPhotonStream_BBEmission :481-516
+              float mu = 0.f, phi = 0.f;
+              const float sel = u01(r[0]);
+              if ((double)sel > p.fracAtms) {  // surface emission :484-493
+                lx = (double)u01(r[1]);
+                ly = (double)u01(r[2]);
+                lz = 0.0;
+                uint32_t r1[4];
+                for (uint32_t j = 0;; j++) {
+                  if ((j & 3u) == 0) philox4x32_10(0u, 1u + (j >> 2), idLo, idHi, p.seedLo, p.seedHi, r1);
+                  mu = sqrtf(u01(pick4(r1, j & 3u)));
+                  if (fabsf(mu) > 2.0f * FLT_MIN) break;
+                }
+                phi = (u01(r[3]) * 2.0f) * 3.14159274f;
+              } else {  // atmosphere :495-510
+                const float rn = u01(r[1]);
+                const long long nxy = (long long)p.nx * p.ny;
+                const int ik = find_cdf(p.voxelCDF + ((long long)p.nx - 1) + (long long)p.nx * (p.ny - 1), p.nz, nxy, rn);
+                const int ij = find_cdf(p.voxelCDF + ((long long)p.nx - 1) + nxy * (ik - 1), p.ny, p.nx, rn);
+                const int ii = find_cdf(p.voxelCDF + (long long)p.nx * ((ij - 1) + (long long)p.ny * (ik - 1)), p.nx, 1, rn);
+                uint32_t r1[4];
+                philox4x32_10(0u, 1u, idLo, idHi, p.seedLo, p.seedHi, r1);
+                lz = ((double)(ik - 1) * 1.0 / (double)p.nz) + (double)(u01(r[2]) / (float)p.nz);
+                if (ik == 1 && lz == 0.0) lz = 2.220446049250313e-16;
+                if (ik == p.nz && lz > 1.0 - 2.0 * 2.220446049250313e-16) lz = lz - 2.0 * 2.220446049250313e-16;
+                lx = ((double)(ii - 1) * 1.0 / (double)p.nx) + (double)(u01(r[3]) * (1.0f / (float)p.nx));
+                ly = ((double)(ij - 1) * 1.0 / (double)p.ny) + (double)(u01(r1[0]) * (1.0f / (float)p.ny));
+                uint32_t r2[4];
+                for (uint32_t j = 0;; j++) {
+                  uint32_t uu;
+                  if (j < 2) uu = j ? r1[3] : r1[2];
+                  else {
+                    if (((j - 2) & 3u) == 0) philox4x32_10(0u, 2u + ((j - 2) >> 2), idLo, idHi, p.seedLo, p.seedHi, r2);
+                    uu = pick4(r2, (j - 2) & 3u);
+                  }
+                  mu = 1.0f - (2.0f * u01(uu));
+                  if (fabsf(mu) > 2.0f * FLT_MIN) break;
+                }
+                phi = (u01(r1[1]) * 2.0f) * 3.14159274f;
+              }
+              const float sinTheta = sqrtf(1.0f - mu * mu);  // makeDirectionCosines :1876-1894
+              dx = sinTheta * cosf(phi); dy = sinTheta * sinf(phi); dz = mu;
+            }
+            w = 1.0f;
+            px = p.x0 + lx * (p.xMax - p.x0);  // :480-482
+            py = p.y0 + ly * (p.yMax - p.y0);
+            if (p.xyRegular) {  // findXYIndicies :1558-1562
+              ix = min((int)((px - p.x0) * p.invDX), p.nx - 1);
+              iy = min((int)((py - p.y0) * p.invDY), p.ny - 1);
+            } else {
+              ix = find_cell(s_edge, p.nx, px);
+              iy = find_cell(s_edge + offY, p.ny, py);
+            }
+            if (p.srcKind == 0) {
+              pz = p.zLaunch; iz = p.izLaunch;
+            } else if (p.zRegular) {  // :485-486
+              pz = p.z0 + lz * (p.zMax - p.z0);
+              iz = min((int)((pz - p.z0) / ((p.zMax - p.z0) / (double)p.nz)), p.nz - 1);
+            } else {  // :491-493 layer-index fraction
+              const double t = (lz - p.z0) * (double)p.nz;
+              const double fl = floor(t);
+              iz = min((int)fl, p.nz - 1);
+              pz = s_edge[offZ + iz] + (t - fl) * (s_edge[offZ + iz + 1] - s_edge[offZ + iz]);
+            }
+            if (p.lwFlag && pz > 0.0)  // :504-508 emission counts as negative absorption
+              atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + (ix + p.nx * (iy + p.ny * iz))), to_fixed(-1.0));
+            needLeg = true;
+          } else {
+            more = false;
+          }
+        }
+      }
+      // ---- out the top, computeRT :573-617: tally in the column the leg left through, free the lane ----
+      if (state == BW_TOP) {
+        const double xw = px + (double)tcur * (double)dx, yw = py + (double)tcur * (double)dy;
+        if (DEBUG) countCrossings(xw, yw, p.nz);
+        const int jx = locX(xw, (spans & 1u) != 0), jy = locY(yw, (spans & 2u) != 0);
+        atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + (jx + p.nx * jy)), weight_to_fixed(w));
+        if (DEBUG) {
+          cTop++;
+          if (p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{0, jx + 1, jy + 1, p.nz + 1, nScat, nLegs, w};
+        }
+        state = BW_DEAD;
+      }
+      // ---- scattering event, computeRT :703-821 ----
+      if (state == BW_COLLIDE) {
+        {  // opticalProperties.f95:1729-1738: the point inside the block where tau is used up
+          const double s = (double)(tcur + div_fast(tau - acc, extCur));
+          px = px + s * (double)dx;
+          py = py + s * (double)dy;
+          pz = pz + s * (double)dz;
+        }
+        // its cell, from the position (the periodic fold moves the position into the domain)
+        {
+          const double xw = px, yw = py;
+          iz = locate_z(s_edge + offZ, p.nz, p.zRegular != 0, p.z0, invDz, pz);
+          if (DEBUG) countCrossings(xw, yw, iz);
+          ix = locX(xw, (spans & 1u) != 0);
+          iy = locY(yw, (spans & 2u) != 0);
+        }
+        const int cell = ix + p.nx * (iy + p.ny * iz);
+        nScat++;
+        if (DEBUG) cColl++;
+        int c = 0;  // component pick :759-760 (findIndex over [0, cumExt(:)]), uniform = slot Z of the leg's block
+        if (p.nc > 1) {
+          for (int k = 0; k < p.nc - 1; k++)
+            if (uZ >= s_cum[k * nvox + cell]) c = k + 1;
+        }
+        const float ssa = s_ssa[c * nvox + cell];
+        const int pfEntry = s_pfi[c * nvox + cell];
+        if (ssa < 1.0f) {  // absorption :765-771
+          atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + cell), weight_to_fixed(w * (1.0f - ssa)));
+          w = w * ssa;
+          if (DEBUG) cAbs++;
+        }
+        if (p.useRR && w < 0.5f) {  // Russian roulette :805-811, RussianRouletteW = 1
+          uint32_t r1[4];
+          philox4x32_10(event, 1u, idLo, idHi, p.seedLo, p.seedHi, r1);
+          if (u01(r1[1]) >= w) { w = 0.0f; if (DEBUG) cKill++; }
+          else { w = 1.0f; if (DEBUG) cSurv++; }
+        }
+        if (w <= FLT_MIN) {  // :812
+          if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{2, ix + 1, iy + 1, iz + 1, nScat, nLegs, 0.0f};
+          state = BW_DEAD;
+        } else {
+          // computeScatteringAngle :1594-1621 (table point count N, floor-type lookup as written)
+          const int n = s_tblNSteps[c];
+          const float *t = tbl + s_tblOffset[c] + (long long)pfEntry * n;
+          const int ai = (int)(uX * (float)n) + 1;
+          float ang;
+          if (ai < n) {
+#ifdef MCBRAT_PRECISE_MATH
+            const float left = uX - (float)(ai - 1) / (float)n;
+#else
+            const float left = uX - (float)(ai - 1) * s_tblInvN[c];
+#endif
+            ang = (1.0f - left) * t[ai - 1] + left * t[ai];
+          } else {
+            ang = t[n - 1];
+          }
+#ifdef MCBRAT_PRECISE_MATH
+          const float cs = cosf(ang);
+#else
+          const float cs = cos_0_pi(ang);
+#endif
+          // next_direct :1921-1948 with (AX, AY)/sqrt(D) = (cos, sin) of a uniform azimuth
+          float AX, AY;
+          sincos_2pi(uY, AX, AY);
+#ifdef MCBRAT_PRECISE_MATH
+          float B = sqrtf(1.0f - cs * cs);
+#else
+          float B = __builtin_amdgcn_sqrtf(1.0f - cs * cs);
+#endif
+          AX = AX * B;
+          AY = AY * B;
+          B = dx * AX - dy * AY;
+          float D = cs - div_fast(B, 1.0f + fabsf(dz));
+          dx = dx * D + AX;
+          dy = dy * D - AY;
+          dz = dz * cs - copysignf(fabsf(B), dz * B);
+          needLeg = true;
+        }
+      }
+      // ---- surface, computeRT :619-676 (Lambertian); fluxDown gets the incident weight :634 ----
+      if (state == BW_SURFACE && doSurface) {
+        {
+          const double xw = px + (double)tcur * (double)dx, yw = py + (double)tcur * (double)dy;  // where the leg met z0 (:1809-1812)
+          if (DEBUG) countCrossings(xw, yw, -1);
+          px = xw; py = yw;
+          ix = locX(xw, true, true);  // (always folded here: the surface description takes the position itself)
+          iy = locY(yw, true, true);
+        }
+        pz = p.zSurf;
+        iz = 0;
+        atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + ncol + (ix + p.nx * iy)), weight_to_fixed(w));
+        nScat++;
+        if (DEBUG) cSurf++;
+        float mu = sqrtf(uX);
+        if (!(fabsf(mu) > 2.0f * FLT_MIN)) {
+          mu = sqrtf(uZ);
+          uint32_t r[4];
+          for (uint32_t j = 0; !(fabsf(mu) > 2.0f * FLT_MIN); j++) {
+            if ((j & 3u) == 0) philox4x32_10(event, 2u + (j >> 2), idLo, idHi, p.seedLo, p.seedHi, r);
+            mu = sqrtf(u01(pick4(r, j & 3u)));
+          }
+        }
+        const float wIn = w;
+        if (p.surfNumX > 0) w = w * surface_reflectance(p, px, py);  // useSurfaceBDRF :667-670
+        else w = (float)((double)w * (double)p.albedo);              // :673
+        if (w <= FLT_MIN) {
+          if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{1, ix + 1, iy + 1, 1, nScat, nLegs, wIn};
+          state = BW_DEAD;
+        } else {
+          const float sinTheta = sqrtf(1.0f - mu * mu);  // makeDirectionCosines(mu, 2 pi Y) :1876-1894
+          float cphi, sphi;
+          sincos_2pi(uY, cphi, sphi);
+          dx = sinTheta * cphi; dy = sinTheta * sphi; dz = mu;
+          needLeg = true;
+        }
+      }
+      // ---- start the next leg: tau, 1/direction, the block the leg starts in ----
+      if (needLeg) {
+        event++;
+        nLegs++;
+        if (DEBUG) {
+          cLegs++;
+          dbgX = unwrapped_index(s_edge, p.nx, p.x0, p.Lx, p.invLx, px);
+          dbgY = unwrapped_index(s_edge + offY, p.ny, p.y0, p.Ly, p.invLy, py);
+          dbgZ = iz;
+        }
+        uint32_t r[4];
+        philox4x32_10(event, 0u, idLo, idHi, p.seedLo, p.seedHi, r);
+#ifdef MCBRAT_PRECISE_MATH
+        tau = -logf(fmaxf(FLT_MIN, u01(r[0])));
+#else
+        tau = -0.693147182f * __builtin_amdgcn_logf(fmaxf(FLT_MIN, u01(r[0])));  // :554
+#endif
+        uX = u01(r[1]); uY = u01(r[2]); uZ = u01(r[3]);
+        acc = 0.0f; tcur = 0.0f;
+        // opticalProperties.f95:1705-1712: huge step for a zero cosine
+        ivx = fabsf(dx) >= 2.0f * FLT_MIN ? rcp_fast(dx) : 0.0f;
+        ivy = fabsf(dy) >= 2.0f * FLT_MIN ? rcp_fast(dy) : 0.0f;
+        ivz = fabsf(dz) >= 2.0f * FLT_MIN ? rcp_fast(dz) : 0.0f;
+        spans = 0;  // (the leg starts inside the domain: its origin was folded where it was located)
+        enterBlock(ix, iy, iz);
+        state = BW_MOVE;
+      }
+      // ---- block crossings: the cell on the other side of the face, from the position; its block ----
+      if (state == BW_CROSS && doCross) {
+        const bool yLtX = tny < tnx;
+        const float m2 = yLtX ? tny : tnx;
+        const bool isZ = tnz < m2;  // (the axis whose face was reached: the same comparison the move made)
+        const double xw = px + (double)tcur * (double)dx, yw = py + (double)tcur * (double)dy, zw = pz + (double)tcur * (double)dz;
+        int jx, jy, jz;
+        if (isZ) {
+          jz = dz >= 0.0f ? fz : fz - 1;  // (0 <= jz < nz: leaving the domain was decided when the face was reached)
+          jx = locX(xw, (spans & 1u) != 0);
+          jy = locY(yw, (spans & 2u) != 0);
+        } else if (yLtX) {
+          jy = dy >= 0.0f ? fy : fy - 1;
+          if (jy >= p.ny) { jy = 0; py -= p.Ly; if (DEBUG) dbgY -= p.ny; }            // periodic y :1790-1796: continue in the next image
+          else if (jy < 0) { jy = p.ny - 1; py += p.Ly; if (DEBUG) dbgY += p.ny; }
+          jx = locX(xw, (spans & 1u) != 0);
+          jz = locate_z(s_edge + offZ, p.nz, p.zRegular != 0, p.z0, invDz, zw);
+        } else {
+          jx = dx >= 0.0f ? fx : fx - 1;
+          if (jx >= p.nx) { jx = 0; px -= p.Lx; if (DEBUG) dbgX -= p.nx; }            // periodic x :1782-1788
+          else if (jx < 0) { jx = p.nx - 1; px += p.Lx; if (DEBUG) dbgX += p.nx; }
+          jy = locY(yw, (spans & 2u) != 0);
+          jz = locate_z(s_edge + offZ, p.nz, p.zRegular != 0, p.z0, invDz, zw);
+        }
+        enterBlock(jx, jy, jz);
+        state = BW_MOVE;
+      }
+      // wave-uniform exit: nothing alive and every lane has already been refused a new photon
+      if (__ballot(state != BW_DEAD || more) == 0ull) break;
+
+      // ---- move: to the collision point inside this block, or to the block face ahead (:1718-1744) ----
+      if (state == BW_MOVE) {
+        const bool yLtX = tny < tnx;
+        const float m2 = yLtX ? tny : tnx;
+        const bool isZ = tnz < m2;
+        const float tmin = isZ ? tnz : m2;
+        const float accNew = acc + (tmin - tcur) * extCur;  // :1743
+        if (accNew > tau) {
+          state = BW_COLLIDE;  // :1729-1738: the stop point is resolved at the head of the next iteration
+        } else if (!(tmin < FLT_MAX)) {
+          state = BW_DEAD;     // no face ahead and nothing to collide with (a horizontal leg through vacuum): the reference walks for ever
+        } else {
+          acc = accNew;
+          tcur = tmin;
+          state = BW_CROSS;
+          if (isZ && fz == (dz >= 0.0f ? p.nz : 0)) state = dz >= 0.0f ? BW_TOP : BW_SURFACE;  // :1801-1812
+        }
+      }
+    }
+
+    // flush this unit's private tallies into the batch slab, once
+    __syncthreads();
+    for (int i = threadIdx.x; i < slabLen; i += BLOCK) {
+      const long long v = s_slab[i];
+      if (v != 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(unitSlab + i), (unsigned long long)v);
+        s_slab[i] = 0;
+      }
+    }
+    if (threadIdx.x == 0) s_cursor[0] = 0;
+    __syncthreads();
+  }
+
+  if (DEBUG && p.counters) {
+    atomicAdd(p.counters + 0, (unsigned long long)cLegs);
+    atomicAdd(p.counters + 1, (unsigned long long)cCross);
+    atomicAdd(p.counters + 2, (unsigned long long)cColl);
+    atomicAdd(p.counters + 3, (unsigned long long)cAbs);
+    atomicAdd(p.counters + 4, (unsigned long long)cTop);
+    atomicAdd(p.counters + 5, (unsigned long long)cSurf);
+    atomicAdd(p.counters + 6, (unsigned long long)cKill);
+    atomicAdd(p.counters + 7, (unsigned long long)cSurv);
+    if (lane == 0) {
+      // slots shared with trace_kernel's report: "walk" = block-crossing phases, "event" = loop iterations
+      atomicAdd(p.counters + 8, wCrossPhases); atomicAdd(p.counters + 9, wCrossLanes);
+      atomicAdd(p.counters + 10, wIters); atomicAdd(p.counters + 11, wEventLanes);
+      atomicAdd(p.counters + 12, wLaunchPhases); atomicAdd(p.counters + 13, wSurfPhases);
+    }
+  }
+}
+
+}  // namespace mcbrat

@@ -55,6 +55,12 @@ struct DevParams {
   const float *bgExt;             // [nz]
   const float *bgCum, *bgSsa;     // [nc][nz]
   const uint16_t *bgPfi;          // [nc][nz]
+  // block walk (LDS-resident grids, mcbrat_blockwalk.hip): axis-aligned blocks of cells with one extinction value
+  int nBlocks;
+  const uint4 *blockRec;          // [nBlocks] {x0 | x1 << 16, y0 | y1 << 16, z0 | z1 << 16, flags}: cell range [lo, hi) per axis;
+                                  // flag bit 0 / 1: the block spans the whole periodic x / y axis (no face on it)
+  const uint16_t *blockOf;        // [nvox] block of each cell
+  int crossThreshold;             // lanes queued before block crossings are served
   // inverse phase-function tables (set_inverse_table)
   const float *tables;            // all components, concatenated, entry-major
   int tblOffset[MCBRAT_MAX_COMPONENTS];

@@ -1,0 +1,14 @@
+#!/bin/bash
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/r02c3
+mkdir -p $OUT
+cd $ROOT
+timeout -k 10 900 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; echo "tests rc=$?"
+tail -15 $OUT/tests.log
+timeout -k 10 300 python scripts/quick_bench.py --case step --bw 1 --block 768 512 --thr 8 16 24 --reps 3 --counters > $OUT/step_ab.log 2>&1
+MCBRAT_CROSS_THRESHOLD=4 timeout -k 10 300 python scripts/quick_bench.py --case step --bw 1 --block 768 --thr 16 --reps 3 >> $OUT/step_ab.log 2>&1
+MCBRAT_CROSS_THRESHOLD=16 timeout -k 10 300 python scripts/quick_bench.py --case step --bw 1 --block 768 --thr 16 --reps 3 >> $OUT/step_ab.log 2>&1
+timeout -k 10 300 python scripts/quick_bench.py --case plane --bw 1 --thr 16 --reps 3 >> $OUT/step_ab.log 2>&1
+grep "case=" $OUT/step_ab.log
+echo finished

@@ -2,8 +2,8 @@
 
     z = (A - B) / sqrt(sigma_A^2 + sigma_B^2),  sigma from the batch variance -- the driver's own estimator
     (Drivers/monteCarloDriver.f95:1188-1219) -- over the three domain means, every column flux and every level of
-    the absorption (heating) profile.  Pass: max |z| < 4 over the bins, |mean z| < 0.2 over the column bins, domain
-    means within the stated number of sigma.
+    the absorption (heating) profile.  Pass: max |z| < max(4, sqrt(2 ln N) + 1) over N bins, |mean z| < 0.2 over the
+    column bins, domain means within the stated number of sigma.
 
 oracle_run() traces a case with the CPU oracle in either of its two generator modes, spread over processes:
     "mt"     -- the reference's MT19937 stream and draw order (one stream per process, seeded (/iseed, proc, 0/) and
@@ -92,7 +92,9 @@ def assert_parity(a, b, label, mean_sigma=4.0, bin_sigma=4.0, mean_z=0.2):
                   max_z_level=float(np.max(np.abs(zp))) if zp.size else 0.0,
                   mean_z_level=float(np.mean(zp)) if zp.size else 0.0, n_level=int(zp.size))
     assert np.max(np.abs(zm)) < mean_sigma, report
-    lim = bin_sigma if zc.size <= 10000 else bin_sigma + 1.0  # (the largest of N unit normals grows like sqrt(2 ln N))
+    # SURVEY.md 8d asks for max |z| < 4 over the bins; the largest of N unit normals grows like sqrt(2 ln N) (3.0 for
+    # 96 bins, 4.0 for 3072, 4.65 for 49 152), so beyond a few hundred bins the limit is that value plus one
+    lim = max(bin_sigma, np.sqrt(2.0 * np.log(max(zc.size, 2))) + 1.0)
     assert np.max(np.abs(zc)) < lim, report
     assert abs(np.mean(zc)) < mean_z + 3.0 / np.sqrt(zc.size), report  # (0.2, plus the sampling error of a mean over few bins)
     assert 0.7 < np.std(zc) < 1.3 or zc.size < 30, report

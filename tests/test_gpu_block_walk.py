@@ -1,0 +1,149 @@
+"""The block walk (mcbrat_blockwalk.hip; domains whose grid lives in LDS): a leg goes from block face to block face,
+where a block is a box of cells with one extinction value, instead of from cell face to cell face.  Against the
+oracle (the reference's face-by-face walk, same Philox streams), against the product's own face-by-face kernel, on a
+medium that is all blocks (step cloud, plane parallel, vacuum) and on one that has none (every cell its own block,
+irregular spacing: the crossing code at every face).  Run on the MI355X box with `-m gpu`."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+SEED = 90210
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mcbrat3d_amd
+    return mcbrat3d_amd
+
+
+def _integ(M, case, block_walk, rr=True, lw=None):
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=10001, useRayTracing=True, useRussianRoulette=rr)
+    integ.setTuning(blockWalk=block_walk)
+    return dom, integ
+
+
+def _same(a, b):
+    return (a["fate"] == b["fate"]) & (a["ix"] == b["ix"]) & (a["iy"] == b["iy"]) & (a["iz"] == b["iz"]) & \
+        (a["nScatter"] == b["nScatter"]) & (np.abs(a["weight"] - b["weight"]) <= 1e-6)
+
+
+def small_random_medium(nx=9, ny=7, nz=11, seed=5, albedo=0.3):
+    """Irregular spacing on every axis, lognormal extinction per cell (no two neighbours alike), a clear slab at the
+    bottom and vacuum cells sprinkled in: small enough to live in LDS, so that the block walk can be forced on it."""
+    rng = np.random.default_rng(seed)
+    xe = np.concatenate([[0.0], np.cumsum(0.04 * 1.07 ** np.arange(nx))])
+    ye = np.concatenate([[0.1], 0.1 + np.cumsum(0.06 * 0.93 ** np.arange(ny))])
+    ze = np.concatenate([[0.0], np.cumsum(0.03 * 1.12 ** np.arange(nz))])
+    ext = np.exp(rng.normal(np.log(5.0), 0.8, (nx, ny, nz)))
+    ext[:, :, :2] = 0.7
+    ext[rng.random((nx, ny, nz)) < 0.1] = 0.0
+    return dict(name="smallRandom", xe=xe, ye=ye, ze=ze, albedo=albedo,
+                components=[dict(ext=ext, ssa=np.where(ext > 0, 0.95, 0.0), pfIndex=np.ones(ext.shape, np.int32),
+                                 legendre=[cases.hg_legendre(0.8, 32)])])
+
+
+@pytest.mark.parametrize("name,case,mu0,phi0,floor", [
+    ("step cloud", cases.step_cloud(0.99), 1.0, 0.0, 0.999),
+    ("step cloud, slant sun, conservative", cases.step_cloud(1.0), 0.5, 30.0, 0.999),
+    ("plane parallel", cases.plane_parallel(ssa=0.9), 0.7, 10.0, 0.999),
+])
+def test_block_walk_fates_against_oracle_and_face_by_face_kernel(M, name, case, mu0, phi0, floor):
+    from oracle import oracle as O
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    n = 200000
+    photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+    dom, integ = _integ(M, case, 1)
+    assert integ.walkMode()["blockWalk"]
+    blk = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+    cb = integ.counters()
+    integ.finalize()
+    dom, integ = _integ(M, case, 0)
+    fbf = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+    cf = integ.counters()
+    integ.finalize()
+    P = cases.oracle_problem(case)
+    ref = O.compute_rt(P, O.solar_source(mu0, phi0), O.philox_rng(SEED, 0), n, want_fates=True)
+    assert _same(blk, ref["fates"]).mean() > floor, _same(blk, ref["fates"]).mean()
+    assert _same(blk, fbf).mean() > floor
+    # what the bench's algorithmic bytes are built from: the block kernel counts the reference's events -- the faces
+    # a leg crosses come from where it starts and ends -- as the face-by-face kernel and the oracle do
+    for k in ("legs", "crossings", "collisions", "absorbEvents", "topExits", "surfaceHits"):
+        assert abs(cb[k] - ref["counters"][k]) <= 2e-3 * max(ref["counters"][k], 1) + 5, (k, cb[k], ref["counters"][k])
+        assert abs(cb[k] - cf[k]) <= 2e-3 * max(cf[k], 1) + 5, (k, cb[k], cf[k])
+
+
+def test_block_walk_forced_on_a_medium_without_blocks(M):
+    """Every cell its own block: the crossing code (cell on the far side of a face from the position, periodic wraps,
+    bisection on irregular edges, vacuum cells, reflecting surface) runs at every face."""
+    from oracle import oracle as O
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = small_random_medium()
+    n = 100000
+    photons = M.new_PhotonStream(0.6, 200.0, numberOfPhotons=10 ** 9)
+    dom, integ = _integ(M, case, 2)
+    got = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+    cnt = integ.counters()
+    P = cases.oracle_problem(case)
+    ref = O.compute_rt(P, O.solar_source(0.6, 200.0), O.philox_rng(SEED, 0), n, want_fates=True)
+    same = _same(got, ref["fates"]).mean()
+    assert same > 0.97, same  # (float rounding of the optical depth differs; every later leg amplifies it)
+    for k in ("legs", "crossings", "collisions", "topExits", "surfaceHits"):
+        assert abs(cnt[k] - ref["counters"][k]) <= 5e-3 * max(ref["counters"][k], 1) + 5, (k, cnt[k], ref["counters"][k])
+    # and one batch's normalised results
+    integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+    res = integ.reportResults()
+    norm = O.normalize(P, n, ref)
+    mu, md, ma, prof = O.report_means(P, norm)
+    for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
+        assert abs(g - r) < 4e-3 * max(r, 0.05), (g, r)
+    assert np.allclose(res["absorbedProfile"], prof, rtol=0.03, atol=2e-5 * np.max(prof) + 1e-9)
+    integ.finalize()
+
+
+def test_block_walk_thermal_source_small_domain(M):
+    """LW emission on an LDS-resident homogeneous domain (one block that spans both periodic axes): launches from the
+    voxel CDF and the surface, emission tallied as negative absorption, against the oracle on the same photons."""
+    from oracle import oracle as O
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.homog_lw(n=6)
+    n = 120000
+    dom = cases.product_domain(case)
+    w = M.new_Weights(dom.numX, dom.numY, dom.numZ)
+    M.emission_weighting(dom, w, case["sfc_temp"])
+    res = {}
+    for bw in (1, 0):
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, LW_flag=1.0)
+        integ.setTuning(blockWalk=bw)
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), M.new_PhotonStream(theseWeights=w, numberOfPhotons=n), n)
+        res[bw] = integ.reportResults()
+        integ.finalize()
+    P = cases.oracle_problem(case, nsteps=9001, lw_flag=1.0)
+    vw, frac, _ = O.emission_weighting(P, case["temps"].transpose(2, 1, 0), case["lambda_um"], case["sfc_temp"])
+    ref = O.compute_radiative_transfer(P, O.EmissionSource(vw, frac), O.philox_rng(SEED, 0), n)
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert abs(res[1][k] - ref[k]) < 40.0 / n, (k, res[1][k], ref[k])
+        assert abs(res[1][k] - res[0][k]) < 40.0 / n, (k, res[1][k], res[0][k])
+
+
+def test_block_walk_is_run_to_run_bitwise_and_split_independent(M):
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = cases.step_cloud(0.99)
+    dom, integ = _integ(M, case, 1)
+    photons = M.new_PhotonStream(1.0, 0.0, numberOfPhotons=10 ** 12)
+
+    def run(calls):
+        integ.resetMoments()
+        for first, ppb, nb in calls:
+            integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED, first), photons, ppb, nb)
+        return integ.moments()
+
+    a = run([(0, 50000, 40)])
+    assert np.array_equal(a, run([(0, 50000, 40)]))
+    b = run([(0, 50000, 15), (750000, 50000, 25)])
+    assert np.array_equal(a[:8], b[:8]) and np.allclose(a, b, rtol=1e-13, atol=1e-9)
+    integ.finalize()

@@ -65,7 +65,7 @@ def test_more_batches_than_workgroups(M):
 def test_private_and_global_tallies_agree_bitwise(M):
     """LDS-private slabs (small domains) and global atomics are both exact integer sums."""
     case = cases.step_cloud(0.99)
-    _, _, _, a = _run(M, case, 0.5, 30.0, 20000, 7, tuning=dict(privateTallies=1))
+    _, _, _, a = _run(M, case, 0.5, 30.0, 20000, 7, tuning=dict(privateTallies=1, blockWalk=0))
     _, _, _, b = _run(M, case, 0.5, 30.0, 20000, 7, tuning=dict(privateTallies=0, blockSize=256, eventThreshold=40))
     assert np.array_equal(a, b)
 

@@ -53,10 +53,11 @@ def test_full_size_properties(M, name, make):
     dz = np.diff(case["ze"])
     assert abs(np.sum(st["absorbedProfile"] * dz) * 1000.0 - st["meanFluxAbsorbed"]) < 2e-5
     assert np.all(st["fluxUp"] >= 0) and np.all(st["fluxDown"] >= 0) and np.all(st["absorbedVolume"] >= 0)
-    # the same photons in two calls of 50 batches (what two ranks would trace): bitwise the same moment arrays --
-    # the finish kernels fold batches in order, tallies are integer sums
+    # the same photons in two calls of 50 batches (what two ranks would trace): the per-batch values are bitwise the
+    # same (integer tallies), the f64 moment sums differ only by the association of the two partial sums
     b = _moments(M, dom, 0.5, 30.0, [(0, ppb, nb // 2), (ppb * (nb // 2), ppb, nb // 2)])
-    assert np.array_equal(a, b)
+    assert np.array_equal(a[:8], b[:8])
+    assert np.allclose(a, b, rtol=1e-13, atol=1e-6)  # (S1 entries are ~1e8 x flux: 1e-6 absolute is 1e-14 relative)
     # run to run
     c = _moments(M, dom, 0.5, 30.0, [(0, ppb, nb)])
     assert np.array_equal(a, c)
