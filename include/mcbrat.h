@@ -146,6 +146,19 @@ int mcbrat_report_intensity(mcbrat_ctx *ctx, float *meanIntensity, float *intens
  * wants to all-reduce it with RCCL binds its own device buffer. */
 int64_t mcbrat_moments_length(const mcbrat_ctx *ctx);
 int mcbrat_bind_moments(mcbrat_ctx *ctx, double *deviceBuffer); /* NULL: library-owned */
+/* The device buffer the moments are accumulated in (library-owned unless one was bound).  Several contexts on one
+ * grid -- one per wavelength of a spectrally integrated run, each with its optical properties resident -- accumulate
+ * into ONE array when the others bind the first one's pointer (monteCarloDriver.f95:1023-1050 keeps one set of
+ * *Stats arrays over all wavelengths).  Calls into contexts that share a buffer must not overlap (synchronous mode). */
+double *mcbrat_moments_device_pointer(mcbrat_ctx *ctx);
+
+/* getFrequencyDistr (src/emissionAndBroadBandWeights.f95:552-572, driver :438-449): the number of photons each of
+ * numLambda wavelengths receives out of totalPhotons, one uniform per photon against the running power CDF
+ * (findCDFIndex: smallest i with U <= CDF(i)).  The reference draws the uniforms from its MT stream in a host loop
+ * over all photons; here draw d of the run is a Philox uniform keyed by `seed` (counter (0xFFFFFFFF, 0, d / 4),
+ * element d % 4; d counts from firstDraw), drawn and counted on the device.  cdf and distribution are host arrays. */
+int mcbrat_frequency_distribution(mcbrat_ctx *ctx, uint64_t seed, uint64_t firstDraw, int32_t numLambda, const double *cdf,
+                                  int64_t totalPhotons, int64_t *distribution);
 int mcbrat_reset_moments(mcbrat_ctx *ctx); /* stream-ordered: enqueued before whatever the context does next; a caller
                                               that reads a bound buffer itself calls mcbrat_synchronize first */
 int mcbrat_get_moments(mcbrat_ctx *ctx, double *hostBuffer);

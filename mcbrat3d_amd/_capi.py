@@ -70,6 +70,8 @@ SYMBOLS = {
     "mcbrat_set_tuning": (C.c_int, [_vp] + [_i32] * 8),
     "mcbrat_set_walk_options": (C.c_int, [_vp, _i32, _i32]),
     "mcbrat_get_walk_mode": (C.c_int, [_vp]),
+    "mcbrat_moments_device_pointer": (_vp, [_vp]),
+    "mcbrat_frequency_distribution": (C.c_int, [_vp, _u64, _u64, _i32, _vp, _i64, _vp]),
     "mcbrat_set_surface_description": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "mcbrat_trace_fates": (C.c_int, [_vp, _u64, _u64, _i64, _vp]),
     "mcbrat_inverse_table_legendre": (C.c_int, [_i32, _vp, _i32, _vp]),

@@ -57,6 +57,115 @@ def frequency_distribution(cdf, totalPhotons, seed=10):
     return rng.multinomial(int(totalPhotons), p / p.sum()).astype(np.int64)
 
 
+def solar_weighting(solarSourceFunction, lambdas, solarMu, spectrRespFunc=None):
+    """solar_Weighting (src/emissionAndBroadBandWeights.f95:149-217): power per wavelength = dLambda x solarMu x source
+    function [x instrument response], dLambda as spectral_widths(), summed with the same compensated running sum,
+    normalised.  Returns (totalPowerCDF, spectrally integrated flux)."""
+    src = np.asarray(solarSourceFunction, np.float64)
+    lam = np.asarray(lambdas, np.float64)
+    if src.size != lam.size or lam.size < 1:
+        raise McbratError("solar_Weighting: source function and wavelengths must have the same length")
+    # (solarMu is a default real in the reference; a single wavelength gets dLambda = 1 as in the thermal branch,
+    #  driver :325-360 -- the reference's own loop would read lambdas(2) there)
+    power = spectral_widths(lam) * float(np.float32(solarMu)) * src
+    if spectrRespFunc is not None:
+        power = power * np.asarray(spectrRespFunc, np.float64)
+    return emitted_flux_cdf(power)
+
+
+def device_frequency_distribution(integrator, cdf, totalPhotons, seed=10, firstDraw=0):
+    """getFrequencyDistr with the draws made and counted on the GPU (mcbrat_frequency_distribution): one uniform per
+    photon against the power CDF, as the reference, without its O(numPhotons) host loop."""
+    return integrator.frequencyDistribution(cdf, totalPhotons, seed, firstDraw)
+
+
+class SpectralRun:
+    """A spectrally integrated run with every wavelength's optical properties RESIDENT on the device: one integrator
+    (context) per wavelength domain, uploaded once by prepare(), all accumulating into one moment array -- the
+    reference re-reads and re-expands the domain of a wavelength for every work unit (read_SSPTable inside the worker
+    loop, Drivers/monteCarloDriver.f95:936).  The loop over (wavelength, batch) units (:889-1085) then only launches
+    kernels.  The photons are split over wavelengths on the device (getFrequencyDistr, driver :438-449)."""
+
+    def __init__(self, M, domains, device=0, **parameters):
+        if not domains:
+            raise McbratError("SpectralRun: no wavelength domains")
+        self.M, self.domains = M, list(domains)
+        self.integrators = [M.new_Integrator(d, device=device) for d in self.domains]
+        for it in self.integrators:
+            it.specifyParameters(**parameters)
+        self.first = self.integrators[0]
+        self._bound = False
+        self.streams, self.counts, self.cdf, self.totalFlux = None, None, None, 0.0
+
+    def _bind(self):
+        if not self._bound:  # (after the parameters are final: intensity directions change the array's length)
+            ptr = self.first.momentsDevicePointer()
+            for it in self.integrators[1:]:
+                it.bindMoments(ptr)
+            self._bound = True
+
+    def prepare_thermal(self, surfaceTemp):
+        """Set-up pass (driver :304-433): emission weights and emitted power of every wavelength, the power CDF; uploads."""
+        widths = spectral_widths([d.lambda_um for d in self.domains])
+        self.streams, fluxes = [], []
+        for dom, it, dl in zip(self.domains, self.integrators, widths):
+            w = new_Weights(dom.numX, dom.numY, dom.numZ)
+            fluxes.append(emission_weighting(dom, w, surfaceTemp, dLambda=dl))
+            it.specifyParameters(LW_flag=1.0)
+            ps = new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 15)
+            it.prepare(dom, ps)
+            self.streams.append(ps)
+        self.cdf, self.totalFlux = emitted_flux_cdf(fluxes)
+        self._bind()
+        return self.totalFlux
+
+    def prepare_solar(self, solarMu, solarAzimuth, solarSourceFunction, lambdas=None, spectrRespFunc=None):
+        """Set-up pass of a solar run (driver :452-505): solar_Weighting; uploads."""
+        lam = [d.lambda_um for d in self.domains] if lambdas is None else lambdas
+        self.cdf, self.totalFlux = solar_weighting(solarSourceFunction, lam, solarMu, spectrRespFunc)
+        self.streams = []
+        for dom, it in zip(self.domains, self.integrators):
+            it.specifyParameters(LW_flag=-1.0)
+            ps = new_PhotonStream(solarMu, solarAzimuth, numberOfPhotons=10 ** 15)
+            it.prepare(dom, ps)
+            self.streams.append(ps)
+        self._bind()
+        return self.totalFlux
+
+    def run(self, numPhotonsPerBatch, numBatches, randomNumbers, seed=10, counts=None):
+        """The worker loop: photons per wavelength from the power CDF (on the device unless `counts` is given), then
+        for every wavelength its photons in batches of numPhotonsPerBatch (+ one smaller batch for the rest).  No host
+        data is touched.  Returns the counts; the moments (shared) are read from any integrator."""
+        if self.streams is None:
+            raise McbratError("SpectralRun: call prepare_thermal or prepare_solar first")
+        total = int(numPhotonsPerBatch) * int(numBatches)
+        self.counts = np.asarray(counts, np.int64) if counts is not None else \
+            device_frequency_distribution(self.first, self.cdf, total, seed)
+        for dom, it, ps, n in zip(self.domains, self.integrators, self.streams, self.counts):
+            full, rest = divmod(int(n), int(numPhotonsPerBatch))
+            ps.currentPhoton = 1
+            if full:
+                it.computeRadiativeTransfer(dom, randomNumbers, ps, int(numPhotonsPerBatch), full)
+            if rest:
+                it.computeRadiativeTransfer(dom, randomNumbers, ps, rest, 1)
+        return self.counts
+
+    def resetMoments(self):
+        self._bind()
+        self.first.resetMoments()
+        self.first.synchronize()
+
+    def moments(self):
+        for it in self.integrators:
+            it.synchronize()
+        return self.first.moments()
+
+    def finalize(self):
+        for it in self.integrators[1:]:
+            it.finalize()
+        self.first.finalize()
+
+
 def run_thermal(integrator, domains, surfaceTemp, numPhotonsPerBatch, numBatches, randomNumbers, seed=10):
     """Thermal (LW_flag >= 0) broadband run over `domains` (one Domain per wavelength, same grid,
     domain.lambda_um set).  Returns (photon counts per wavelength, spectrally integrated flux).

@@ -1118,6 +1118,45 @@ int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip, int32_t blockWalk)
   return 0;
 }
 
+double *mcbrat_moments_device_pointer(mcbrat_ctx *c) {
+  if (!c || !c->haveGrid) return nullptr;
+  (void)hipSetDevice(c->device);
+  if (ensure_moments(c)) return nullptr;
+  return c->dMoments;
+}
+
+int mcbrat_frequency_distribution(mcbrat_ctx *c, uint64_t seed, uint64_t firstDraw, int32_t numLambda, const double *cdf,
+                                  int64_t totalPhotons, int64_t *distribution) {
+  if (!c) return 1;
+  if (numLambda < 1 || !cdf || !distribution || totalPhotons < 0) return fail(c, "getFrequencyDistr: invalid arguments.");
+  for (int i = 1; i < numLambda; ++i)
+    if (!(cdf[i] >= cdf[i - 1])) return fail(c, "getFrequencyDistr: the power CDF must not decrease.");
+  (void)hipSetDevice(c->device);
+  if (init_lane(c, 0)) return 1;
+  hipStream_t st = c->lane[0].stream;
+  double *dCdf = nullptr;
+  unsigned long long *dCounts = nullptr;
+  HIP_OK(c, hipMalloc((void **)&dCdf, sizeof(double) * numLambda));
+  HIP_OK(c, hipMalloc((void **)&dCounts, sizeof(unsigned long long) * numLambda));
+  HIP_OK(c, hipMemcpyAsync(dCdf, cdf, sizeof(double) * numLambda, hipMemcpyHostToDevice, st));
+  HIP_OK(c, hipMemsetAsync(dCounts, 0, sizeof(unsigned long long) * numLambda, st));
+  if (totalPhotons > 0) {
+    const unsigned long long blocks4 = ((unsigned long long)totalPhotons + 3) / 4 + 1;
+    const unsigned grid = (unsigned)std::min<unsigned long long>((blocks4 + 255) / 256, (unsigned long long)c->numCUs * 8);
+    const size_t lds = numLambda <= 8192 ? sizeof(unsigned) * (size_t)numLambda : 0;
+    hipLaunchKernelGGL(frequency_distribution_kernel, dim3(std::max(1u, grid)), dim3(256), lds, st, dCdf, numLambda,
+                       (unsigned long long)totalPhotons, (unsigned long long)firstDraw, (uint32_t)seed, (uint32_t)(seed >> 32), dCounts);
+    HIP_OK(c, hipGetLastError());
+  }
+  std::vector<unsigned long long> h(numLambda);
+  HIP_OK(c, hipMemcpyAsync(h.data(), dCounts, sizeof(unsigned long long) * numLambda, hipMemcpyDeviceToHost, st));
+  HIP_OK(c, hipStreamSynchronize(st));
+  for (int i = 0; i < numLambda; ++i) distribution[i] = (int64_t)h[i];
+  (void)hipFree(dCdf);
+  (void)hipFree(dCounts);
+  return 0;
+}
+
 int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0)) : 0; }
 
 int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int64_t ppb, int32_t nBatches,

@@ -199,15 +199,64 @@ trace_block_kernel(const DevParams p) {
     for (;;) {
       bool needLeg = false;
       int ix = 0, iy = 0, iz = 0;  // cell of a lane that starts a leg in this iteration
-      // Rare kinds of work wait until enough lanes ask for them -- or until the wave has little else to do.
-      const unsigned long long mDead = __ballot(state == BW_DEAD && more);
-      const unsigned long long mSurf = __ballot(state == BW_SURFACE);
+      // Rare kinds of work -- exits, launches, block crossings -- wait until enough lanes ask for them, or until the
+      // wave has little else to do.  Exits come first and launches right after them: under a black surface every exit
+      // frees its lane, so the lanes that have just left are refilled in the same iteration instead of queueing again.
+      const unsigned long long mSurf = __ballot(state == BW_SURFACE || state == BW_TOP);  // exits, served together
       const unsigned long long mCross = __ballot(state == BW_CROSS);
-      const int nBusy = __popcll(__ballot(state == BW_COLLIDE || state == BW_TOP));
+      const int nBusy = __popcll(__ballot(state == BW_COLLIDE));
       const bool idle = nBusy < p.eventThreshold;
-      const bool doLaunch = __popcll(mDead) >= p.launchThreshold || idle;
       const bool doSurface = __popcll(mSurf) >= p.surfaceThreshold || idle;
       const bool doCross = __popcll(mCross) >= p.crossThreshold || idle;
+      // ---- exits: out the top (computeRT :573-617) or down to the surface (:619-676, Lambertian) ----
+      // Both need the column the leg left through, from the position; fluxDown gets the incident weight (:634).
+      if ((state == BW_SURFACE || state == BW_TOP) && doSurface) {
+        const bool top = state == BW_TOP;
+        {
+          const double xw = px + (double)tcur * (double)dx, yw = py + (double)tcur * (double)dy;  // where the leg met the face (:1801-1812)
+          if (DEBUG) countCrossings(xw, yw, top ? p.nz : -1);
+          px = xw; py = yw;
+          ix = locX(xw, true, true);  // (always folded here: the surface description takes the position itself)
+          iy = locY(yw, true, true);
+        }
+        atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + (top ? 0 : ncol) + (ix + p.nx * iy)), weight_to_fixed(w));
+        if (top) {
+          if (DEBUG) {
+            cTop++;
+            if (p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{0, ix + 1, iy + 1, p.nz + 1, nScat, nLegs, w};
+          }
+          state = BW_DEAD;
+        } else {
+          pz = p.zSurf;
+          iz = 0;
+          nScat++;
+          if (DEBUG) cSurf++;
+          float mu = sqrtf(uX);
+          if (!(fabsf(mu) > 2.0f * FLT_MIN)) {
+            mu = sqrtf(uZ);
+            uint32_t r[4];
+            for (uint32_t j = 0; !(fabsf(mu) > 2.0f * FLT_MIN); j++) {
+              if ((j & 3u) == 0) philox4x32_10(event, 2u + (j >> 2), idLo, idHi, p.seedLo, p.seedHi, r);
+              mu = sqrtf(u01(pick4(r, j & 3u)));
+            }
+          }
+          const float wIn = w;
+          if (p.surfNumX > 0) w = w * surface_reflectance(p, px, py);  // useSurfaceBDRF :667-670
+          else w = (float)((double)w * (double)p.albedo);              // :673
+          if (w <= FLT_MIN) {
+            if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{1, ix + 1, iy + 1, 1, nScat, nLegs, wIn};
+            state = BW_DEAD;
+          } else {
+            const float sinTheta = sqrtf(1.0f - mu * mu);  // makeDirectionCosines(mu, 2 pi Y) :1876-1894
+            float cphi, sphi;
+            sincos_2pi(uY, cphi, sphi);
+            dx = sinTheta * cphi; dy = sinTheta * sphi; dz = mu;
+            needLeg = true;
+          }
+        }
+      }
+      const unsigned long long mDead = __ballot(state == BW_DEAD && more);
+      const bool doLaunch = __popcll(mDead) >= p.launchThreshold || idle;
       const unsigned long long want = doLaunch ? mDead : 0ull;
       if (DEBUG) {
         wIters++;
@@ -311,18 +360,6 @@ trace_block_kernel(const DevParams p) {
           }
         }
       }
-      // ---- out the top, computeRT :573-617: tally in the column the leg left through, free the lane ----
-      if (state == BW_TOP) {
-        const double xw = px + (double)tcur * (double)dx, yw = py + (double)tcur * (double)dy;
-        if (DEBUG) countCrossings(xw, yw, p.nz);
-        const int jx = locX(xw, (spans & 1u) != 0), jy = locY(yw, (spans & 2u) != 0);
-        atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + (jx + p.nx * jy)), weight_to_fixed(w));
-        if (DEBUG) {
-          cTop++;
-          if (p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{0, jx + 1, jy + 1, p.nz + 1, nScat, nLegs, w};
-        }
-        state = BW_DEAD;
-      }
       // ---- scattering event, computeRT :703-821 ----
       if (state == BW_COLLIDE) {
         {  // opticalProperties.f95:1729-1738: the point inside the block where tau is used up
@@ -399,43 +436,6 @@ trace_block_kernel(const DevParams p) {
           dx = dx * D + AX;
           dy = dy * D - AY;
           dz = dz * cs - copysignf(fabsf(B), dz * B);
-          needLeg = true;
-        }
-      }
-      // ---- surface, computeRT :619-676 (Lambertian); fluxDown gets the incident weight :634 ----
-      if (state == BW_SURFACE && doSurface) {
-        {
-          const double xw = px + (double)tcur * (double)dx, yw = py + (double)tcur * (double)dy;  // where the leg met z0 (:1809-1812)
-          if (DEBUG) countCrossings(xw, yw, -1);
-          px = xw; py = yw;
-          ix = locX(xw, true, true);  // (always folded here: the surface description takes the position itself)
-          iy = locY(yw, true, true);
-        }
-        pz = p.zSurf;
-        iz = 0;
-        atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + ncol + (ix + p.nx * iy)), weight_to_fixed(w));
-        nScat++;
-        if (DEBUG) cSurf++;
-        float mu = sqrtf(uX);
-        if (!(fabsf(mu) > 2.0f * FLT_MIN)) {
-          mu = sqrtf(uZ);
-          uint32_t r[4];
-          for (uint32_t j = 0; !(fabsf(mu) > 2.0f * FLT_MIN); j++) {
-            if ((j & 3u) == 0) philox4x32_10(event, 2u + (j >> 2), idLo, idHi, p.seedLo, p.seedHi, r);
-            mu = sqrtf(u01(pick4(r, j & 3u)));
-          }
-        }
-        const float wIn = w;
-        if (p.surfNumX > 0) w = w * surface_reflectance(p, px, py);  // useSurfaceBDRF :667-670
-        else w = (float)((double)w * (double)p.albedo);              // :673
-        if (w <= FLT_MIN) {
-          if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{1, ix + 1, iy + 1, 1, nScat, nLegs, wIn};
-          state = BW_DEAD;
-        } else {
-          const float sinTheta = sqrtf(1.0f - mu * mu);  // makeDirectionCosines(mu, 2 pi Y) :1876-1894
-          float cphi, sphi;
-          sincos_2pi(uY, cphi, sphi);
-          dx = sinTheta * cphi; dy = sinTheta * sphi; dz = mu;
           needLeg = true;
         }
       }

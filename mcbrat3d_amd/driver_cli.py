@@ -21,8 +21,8 @@ DEFAULTS = {  # monteCarloDriver.f95:58-99
                        hybridphasefunwidth=7.0, numordersorigphasefunintencalcs=0, userussianrouletteforintensity=True,
                        zetamin=0.3, limitintensitycontributions=False, maxintensitycontribution=77.0),
     "output": dict(reportvolumeabsorption=False, reportabsorptionprofile=False),
-    "filenames": dict(physdomainfile="", domainfilename="", outputfluxfile="", outputabsproffile="", outputabsvolumefile="",
-                      outputnetcdffile="", outputradfile=""),
+    "filenames": dict(physdomainfile="", domainfilename="", sspfilename="", solarsourcefile="", instrresponsefile="",
+                      outputfluxfile="", outputabsproffile="", outputabsvolumefile="", outputnetcdffile="", outputradfile=""),
 }
 
 
@@ -138,6 +138,71 @@ def builtin_domain(name):
     return dom
 
 
+def load_domains(cfg):
+    """The optical domain of every wavelength of the run.  The current driver's file family (monteCarloDriver.f95:299,
+    :936): `physDomainFile` (read_Common) + up to four `SSPfilename` tables (read_SSPTable), numLambda wavelengths,
+    Rayleigh scattering added when calcRayl.  Otherwise one domain: a `.dom` file (read_Domain) or a built-in I3RC
+    generator ("builtin:i3rcStepCloud")."""
+    from mcbrat3d_amd import ncio
+    ssp = cfg["sspfilename"]
+    ssp = [ssp] if isinstance(ssp, str) else list(ssp)
+    ssp = [n for n in ssp if n]
+    if ssp:
+        if not cfg["physdomainfile"]:
+            raise SystemExit("SSPfilename given without physDomainFile")
+        common = ncio.read_Common(cfg["physdomainfile"])
+        return [ncio.read_SSPTable(ssp, i, common, setup=False, calcRayl=bool(cfg["calcrayl"]))
+                for i in range(1, int(cfg["numlambda"]) + 1)]
+    domfile = cfg["physdomainfile"] or cfg["domainfilename"]
+    dom = builtin_domain(domfile[8:]) if domfile.startswith("builtin:") else ncio.read_Domain(domfile)
+    dom.getOpticalPropertiesByComponent()
+    return [dom]
+
+
+def run_spectral(cfg, doms, rank, world, local, dist):
+    """Spectrally integrated run (numLambda > 1, or thermal emission): every wavelength resident on the GPU
+    (broadband.SpectralRun), photons split over wavelengths on the device, ranks take contiguous blocks of batches."""
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd import broadband, driver, ncio
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    run = broadband.SpectralRun(M, doms, device=local, minInverseTableSize=cfg["nphaseintervals"],
+                                useRayTracing=cfg["useraytracing"], useRussianRoulette=cfg["userussianroulette"])
+    if cfg["lw_flag"] >= 0:
+        flux = run.prepare_thermal(cfg["surfacetemp"])
+    else:
+        nlam = len(doms)
+        if not cfg["solarsourcefile"]:
+            raise SystemExit("a solar run over several wavelengths needs solarSourceFile")
+        src, lam = ncio.read_SolarSource(cfg["solarsourcefile"], nlam)
+        srf = ncio.read_specResponseFunction(cfg["instrresponsefile"], nlam) if cfg["instrresponsefile"] else None
+        flux = run.prepare_solar(cfg["solarmu"], cfg["solarazimuth"], src, lam, srf)
+    ppb, nbAll = int(cfg["numphotonsperbatch"]), int(cfg["numbatches"])
+    lo, nb = driver.split_batches(nbAll, rank, world)
+    moments = None
+    if dist is not None:
+        import torch
+        moments = torch.zeros(8 + 2 * run.first.momentsLength(), dtype=torch.float64, device="cuda:%d" % local)
+        run.first.bindMoments(moments.data_ptr())
+    run.resetMoments()
+    if nb > 0:
+        # this rank's photons: ids and wavelength draws [lo * ppb, (lo + nb) * ppb)
+        counts = broadband.device_frequency_distribution(run.first, run.cdf, ppb * nb, cfg["iseed"], firstDraw=lo * ppb)
+        run.run(ppb, nb, new_RandomNumberSequence(cfg["iseed"], lo * ppb), seed=cfg["iseed"], counts=counts)
+    for it in run.integrators:
+        it.synchronize()
+    if dist is not None and world > 1:
+        import torch
+        dist.all_reduce(moments, op=dist.ReduceOp.SUM)  # sumAcrossProcesses, monteCarloDriver.f95:1151-1166
+        torch.cuda.synchronize()
+        buf = moments.cpu().numpy()
+    else:
+        buf = run.moments()
+    nx, ny, nz = run.first._dims
+    stats = driver.statistics(driver.unpack_moments(buf, nx, ny, nz), solarFlux=flux)
+    run.finalize()
+    return stats, flux
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     if len(argv) != 1:
@@ -146,8 +211,6 @@ def main(argv=None):
     cfg = read_namelists(argv[0])
     if cfg["numphotonsperbatch"] <= 0:
         raise SystemExit("must specify numPhotonsPerBatch")
-    if cfg["lw_flag"] >= 0:
-        raise SystemExit("thermal runs: use mcbrat3d_amd.broadband.run_thermal (this CLI is monochromatic solar)")
     import mcbrat3d_amd as M
     from mcbrat3d_amd import driver, ncio
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
@@ -159,8 +222,27 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     domfile = cfg["physdomainfile"] or cfg["domainfilename"]
-    dom = builtin_domain(domfile[8:]) if domfile.startswith("builtin:") else ncio.read_Domain(domfile)
-    dom.getOpticalPropertiesByComponent()
+    doms = load_domains(cfg)
+    dom = doms[0]
+    if len(doms) > 1 or cfg["lw_flag"] >= 0:
+        setup = time.time() - t0
+        stats, flux = run_spectral(cfg, doms, rank, world, local, dist)
+        if rank == 0:
+            print(" spectrally integrated flux %.6g; mean flux up/down/absorbed: " % flux +
+                  "  ".join("%9.6f +-%9.6f" % (stats[k], stats[k + "_StdErr"]) for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed")))
+            xe, ye, ze = dom.xPosition, dom.yPosition, dom.zPosition
+            if cfg["outputfluxfile"]:
+                writeResults_ASCII(cfg["outputfluxfile"], cfg, domfile, stats, xe, ye, ze, flux, dom.surfaceAlbedo)
+            if cfg["outputnetcdffile"]:
+                ncio.writeResults_netcdf(cfg["outputnetcdffile"], domfile, stats, xe, ye, ze, solarFlux=flux, solarMu=cfg["solarmu"],
+                                         solarAzimuth=cfg["solarazimuth"], surfaceAlbedo=dom.surfaceAlbedo, iseed=cfg["iseed"],
+                                         nPhaseIntervals=cfg["nphaseintervals"], reportAbsorptionProfile=cfg["reportabsorptionprofile"],
+                                         reportVolumeAbsorption=cfg["reportvolumeabsorption"], cpuTimeTotal=time.time() - t0,
+                                         cpuTimeSetup=setup, numProcs=world)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return stats
     integ = M.new_Integrator(dom, device=local)
     integ.specifyParameters(minInverseTableSize=cfg["nphaseintervals"], useRayTracing=cfg["useraytracing"],
                             useRussianRoulette=cfg["userussianroulette"], LW_flag=cfg["lw_flag"])

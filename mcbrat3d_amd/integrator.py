@@ -288,6 +288,14 @@ class Integrator:
             self._loaded_weights = photons.weights
         self._source_token = token
 
+    def prepare(self, thisDomain, incomingPhotons):
+        """Everything computeRadiativeTransfer would upload for this domain and source -- optical grids, inverse (and
+        forward) tables, emission CDF -- now, so that later calls with the same objects trace without touching the host
+        data again (spectrally integrated runs keep one prepared integrator per wavelength)."""
+        self.specifyParameters()
+        self._load_domain(thisDomain)
+        self._load_source(incomingPhotons)
+
     def computeRadiativeTransfer(self, thisDomain, randomNumbers, incomingPhotons, numPhotonsPerBatch, numBatches=1):
         """Traces numBatches batches of numPhotonsPerBatch photons (the reference call is
         numBatches = 1).  Returns numPhotonsProcessed.  reportResults() then returns the
@@ -335,6 +343,21 @@ class Integrator:
 
     def bindMoments(self, device_ptr):
         self._check(self._lib.mcbrat_bind_moments(self._ctx, C.c_void_p(device_ptr)))
+
+    def momentsDevicePointer(self):
+        """Device address of the moment array in use (to be bound by the integrators of the other wavelengths)."""
+        ptr_ = self._lib.mcbrat_moments_device_pointer(self._ctx)
+        if not ptr_:
+            raise McbratError("moments: no moment array (grid not set)")
+        return int(ptr_)
+
+    def frequencyDistribution(self, cdf, totalPhotons, seed=10, firstDraw=0):
+        """getFrequencyDistr on the device: photons per wavelength (one uniform per photon against the power CDF)."""
+        cdf = np.ascontiguousarray(cdf, np.float64)
+        out = np.zeros(cdf.size, np.int64)
+        self._check(self._lib.mcbrat_frequency_distribution(self._ctx, int(seed) & 0xFFFFFFFFFFFFFFFF, int(firstDraw), int(cdf.size),
+                                                            ptr(cdf), int(totalPhotons), ptr(out)))
+        return out
 
     def resetMoments(self):
         self._check(self._lib.mcbrat_reset_moments(self._ctx))

@@ -202,3 +202,237 @@ def writeResults_netcdf(outputFileName, domainFileName, stats, xPosition, yPosit
     finally:
         f.close()
     return outputFileName
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The file family the current driver reads (Drivers/monteCarloDriver.f95:299, :936): a physical-properties file
+# (read_Common) plus up to four single-scattering-property table files (read_SSPTable).  Names are spelled as
+# those readers spell them -- lower-case "x-edges", "ExtinctionT" -- which is NOT how write_Domain spells them
+# ("x-Edges", "extinctionT"): the two families do not read each other's files.
+# ------------------------------------------------------------------------------------------------------------
+LIGHT_SPD = 2.99792458E8   # [m/s]   opticalProperties.f95:27-29
+AVOGADRO = 6.02214129E23   # [mol^-1]
+RSTAR = 8.3144621          # [J K^-1 mol^-1]
+
+
+class CommonDomain:
+    """type(commonDomain), opticalProperties.f95:63-75: what all wavelengths share."""
+
+    def __init__(self, xPosition, yPosition, zPosition, temps, numConc=None, massConc=None, Reff=None, rho=None):
+        self.xPosition = np.ascontiguousarray(xPosition, np.float64)
+        self.yPosition = np.ascontiguousarray(yPosition, np.float64)
+        self.zPosition = np.ascontiguousarray(zPosition, np.float64)
+        self.temps, self.numConc, self.massConc, self.Reff, self.rho = temps, numConc, massConc, Reff, rho
+
+
+def _xyz(a):
+    """NetCDF (z, y, x) -> Fortran index order [ix, iy, iz]."""
+    return np.array(a, np.float64).transpose(2, 1, 0)
+
+
+def read_Common(fileName):
+    """read_Common, src/opticalProperties.f95:347-451."""
+    try:
+        f = netcdf_file(fileName, "r", mmap=False)
+    except (OSError, TypeError, ValueError):
+        raise McbratError("read_Common: Can't open file " + str(fileName))
+    try:
+        for d in ("x-edges", "y-edges", "z-edges", "z-grid"):
+            if d not in f.dimensions:
+                raise McbratError("read_Common: %s problem reading dimensions." % fileName)
+        for v in ("x-edges", "y-edges", "z-edges", "Temperatures"):
+            if v not in f.variables:
+                raise McbratError("read_Common: %s doesn't look an optical properties file." % fileName)
+        xe, ye, ze = (np.array(f.variables[k][:], np.float64) for k in ("x-edges", "y-edges", "z-edges"))
+        nx, ny, nz = len(xe) - 1, len(ye) - 1, len(ze) - 1
+        c = CommonDomain(xe, ye, ze, _xyz(f.variables["Temperatures"][:]))
+
+        def spread(var, what):  # 3-D as stored, or a profile copied to every column (:401-410, :436-444)
+            a = np.array(var[:], np.float64)
+            if a.ndim == 3:
+                return a.transpose(2, 1, 0)
+            if a.ndim == 1:
+                return np.broadcast_to(a[None, None, :], (nx, ny, nz)).copy()
+            raise McbratError("read_Common: %s strange number of dimensions for %s" % (fileName, what))
+
+        if "Pressures" in f.variables:  # hPa -> molecules m^-3 (:424)
+            prssr = spread(f.variables["Pressures"], "pressure")
+            c.numConc = (prssr * 100.0 * AVOGADRO) / (RSTAR * c.temps)
+            if "nonGasComps" in f.dimensions and f.dimensions["nonGasComps"]:
+                if "massConc" not in f.variables or "Reff" not in f.variables:
+                    raise McbratError("read_Common: %s problem reading DENSITY, massConc, or Reff." % fileName)
+                # Fortran (component, x, y, z) = NetCDF (z, y, x, component)
+                c.massConc = np.array(f.variables["massConc"][:], np.float64).transpose(3, 2, 1, 0)
+                c.Reff = np.array(f.variables["Reff"][:], np.float64).transpose(3, 2, 1, 0)
+        if "Density" in f.variables:
+            c.rho = spread(f.variables["Density"], "density")
+        return c
+    finally:
+        f.close()
+
+
+def calc_RayleighScattering(lambda_um, rho, N):
+    """calc_RayleighScattering, src/opticalProperties.f95:2052-2086: (extinction [km^-1], ssa, phase index, table) of the
+    molecular atmosphere from the density and number-concentration profiles."""
+    Pi = float(np.float32(3.14159265358979312))  # (the module's Pi is a default real, :26)
+    f, rho0 = 1.060816681, 1.275
+    lam = float(lambda_um)
+    mr1 = 6.4328E-5 + (2.94981E-2 / (146 - (lam ** (-2)))) + (2.554E-4 / (41 - (lam ** (-2))))
+    rho, N = np.asarray(rho, np.float64), np.asarray(N, np.float64)
+    ext = (32.0E27) * f * (Pi ** 3) * (rho ** 2) * (mr1 ** 2) / (3.0 * N * (rho0 ** 2) * (lam ** 4))
+    LG = (np.array([0.0, 0.5], np.float32) / np.array([2.0 * 1.0 + 1.0, 2.0 * 2.0 + 1.0], np.float32)).astype(np.float32)
+    table = PhaseFunctionTable([PhaseFunction(legendreCoefficients=LG)], np.zeros(1, np.float32), "Rayleigh Scattering")
+    return ext, np.ones_like(ext), np.ones(ext.shape, np.int32), table
+
+
+def _read_PhaseFunctionTableNEW(f, p, spectIndex):
+    """read_PhaseFunctionTableNEW, src/scatteringPhaseFunctions.f95:1279-1440: the table of ONE spectral index out of a
+    file whose extinctionT / ssaT / start / length / legendreCoefficients carry a spectral dimension."""
+    att = p + "phaseFunctionStorageType"
+    if not hasattr(f, att):
+        raise McbratError("read_PhaseFunctionTable: file doesn't contain this phase function.")
+    storage = getattr(f, att)
+    storage = storage.decode() if isinstance(storage, bytes) else storage
+    k = spectIndex - 1
+    key = np.array(f.variables[p + "phaseFunctionKeyT"][:], np.float32)
+    ext = np.array(f.variables[p + "ExtinctionT"][:], np.float64)[k]                  # Fortran (entry, lambda)
+    ssa = np.array(f.variables[p + "SingleScatteringAlbedoT"][:], np.float64)[k]
+    desc = getattr(f, p + "description", b"")
+    desc = desc.decode() if isinstance(desc, bytes) else desc
+    pfs = []
+    if storage.startswith("Angle-Value"):
+        ang = np.array(f.variables[p + "scatteringAngle"][:], np.float32)
+        vals = np.array(f.variables[p + "phaseFunctionValues"][:], np.float32)      # Fortran (angle, entry)
+        for v, e, w in zip(vals, ext, ssa):
+            pfs.append(PhaseFunction(scatteringAngle=ang.copy(), value=v.copy(), extinction=float(e), singleScatteringAlbedo=float(w)))
+    elif storage.startswith("LegendreCoefficients"):
+        start = np.array(f.variables[p + "start"][:], np.int64)[k]
+        length = np.array(f.variables[p + "length"][:], np.int64)[k]
+        coeffs = np.array(f.variables[p + "legendreCoefficients"][:], np.float32)[k]  # Fortran (coefficient, lambda)
+        first = int(start[0])  # the coefficients of this index are read from start(1) on, starts renumbered from 1 (:1379-1382)
+        block = coeffs[first - 1:first - 1 + int(length.sum())]
+        start = start - first + 1
+        for s, n, e, w in zip(start, length, ext, ssa):
+            pfs.append(PhaseFunction(legendreCoefficients=block[s - 1:s - 1 + n].copy(), extinction=float(e), singleScatteringAlbedo=float(w)))
+    else:
+        raise McbratError("read_PhaseFunctionTable: file is of unknown format.")
+    return PhaseFunctionTable(pfs, key, desc)
+
+
+def read_SSPTable(fileNames, lambdaIndex, commonD, setup=False, calcRayl=True):
+    """read_SSPTable, src/opticalProperties.f95:147-345: the optical domain of wavelength `lambdaIndex` (1-based) from
+    the common physical domain and up to four single-scattering-property table files.  Gaseous components
+    (`extType = "absXsec"`): absorption cross-section profile x number concentration; condensed components
+    (`"volExt"`): mass concentration x the table's extinction interpolated in effective radius, the phase function of
+    the nearer table entry.  `setup`: only what emission weighting needs (no phase functions, no Rayleigh)."""
+    if isinstance(fileNames, str):
+        fileNames = [fileNames]
+    nx, ny, nz = len(commonD.xPosition) - 1, len(commonD.yPosition) - 1, len(commonD.zPosition) - 1
+    dom = None
+    comp, gasComp = 1, 0  # counters over all files (:177-178)
+    for fileName in [n for n in fileNames if n]:
+        try:
+            f = netcdf_file(fileName, "r", mmap=False)
+        except (OSError, TypeError, ValueError):
+            raise McbratError("read_SSPTable: Can't open file " + str(fileName))
+        try:
+            if "f_grid_nelem" not in f.dimensions or "f_grid" not in f.variables or "surfaceAlbedo" not in f.variables:
+                raise McbratError("read_SSPTable: doesn't look an optical properties file.")
+            nLambda = int(f.dimensions["f_grid_nelem"])
+            if not (1 <= lambdaIndex <= nLambda):
+                raise McbratError("read_SSPTable: Error reading scalar fields from file")
+            freq = float(np.array(f.variables["f_grid"][:], np.float64)[lambdaIndex - 1])
+            lam = (LIGHT_SPD * (10 ** 6)) / freq  # [microns] :194
+            albedo = float(np.array(f.variables["surfaceAlbedo"][:], np.float64)[lambdaIndex - 1])
+            if dom is None:  # new_DomainBB(commonD, lambda, lambdaIndex, nlambda, albedo) :203
+                dom = Domain(commonD.xPosition, commonD.yPosition, commonD.zPosition, temps=commonD.temps,
+                             surfaceAlbedo=albedo, lambda_um=lam)
+                dom.lambdaIndex, dom.numberOfLambdas = int(lambdaIndex), nLambda
+            for i in range(1, int(getattr(f, "numberOfComponents")) + 1):
+                p = _prefix(i)
+                name = getattr(f, p + "Name")
+                name = name.decode() if isinstance(name, bytes) else name
+                zLevelBase = int(getattr(f, p + "zLevelBase"))
+                extType = getattr(f, p + "extType")
+                extType = (extType.decode() if isinstance(extType, bytes) else extType).strip()
+                if extType == "absXsec":  # :216-236 a gas: absorption only
+                    if commonD.numConc is None:
+                        raise McbratError("read_SSPTable: Error reading scalar fields from file")
+                    gasComp += 1
+                    xsec = np.array(f.variables[p + "xsec"][:], np.float64)[lambdaIndex - 1]  # Fortran (z, lambda)
+                    ext = xsec * commonD.numConc[0, 0, :] * 1000.0  # m^2 x m^-3 -> km^-1
+                    ssa = np.zeros(nz)
+                    pfi = np.ones(nz, np.int32)
+                    table = PhaseFunctionTable([PhaseFunction(legendreCoefficients=np.zeros(2, np.float32))],
+                                               np.zeros(1, np.float32), "Molecular Absorption")
+                elif extType == "volExt":  # :237-303
+                    if commonD.massConc is None or commonD.Reff is None:
+                        raise McbratError("read_SSPTable: Error reading scalar fields from file")
+                    key = np.array(f.variables[p + "phaseFunctionKeyT"][:], np.float32)
+                    extT = np.array(f.variables[p + "ExtinctionT"][:], np.float64)[lambdaIndex - 1]
+                    ssaT = np.array(f.variables[p + "SingleScatteringAlbedoT"][:], np.float64)[lambdaIndex - 1]
+                    if setup:
+                        table = PhaseFunctionTable([PhaseFunction(legendreCoefficients=np.zeros(2, np.float32))],
+                                                   np.zeros(1, np.float32), "dummy table")
+                    else:
+                        table = _read_PhaseFunctionTableNEW(f, p, lambdaIndex)
+                    mass = commonD.massConc[comp - gasComp - 1]
+                    reff = commonD.Reff[comp - gasComp - 1]
+                    key8 = key.astype(np.float64)
+                    inside = (mass > 0.0) & (reff < key8.max()) & (reff >= key8.min())
+                    if np.any((mass > 0.0) & ~inside):
+                        raise McbratError("read_SSPTable: Effective radius outside of table range")
+                    il = np.clip(np.searchsorted(key8, reff, side="right"), 1, len(key8) - 1)  # findIndex: key(il) <= Reff < key(il+1)
+                    fr = (reff - key8[il - 1]) / (key8[il] - key8[il - 1])
+                    ext = np.where(inside, mass * ((1 - fr) * extT[il - 1] + fr * extT[il]), 0.0)
+                    ssa = np.where(inside, (1 - fr) * ssaT[il - 1] + fr * ssaT[il], 0.0)
+                    pfi = np.ones((nx, ny, nz), np.int32)
+                    if not setup:  # the closer phase function :289-296
+                        pfi = np.where(inside, np.where(fr < 0.5, il, il + 1), 1).astype(np.int32)
+                else:
+                    raise McbratError("read_SSPTable: unrecognizable extType")
+                dom.addOpticalComponent(name, ext, ssa, pfi, table, zLevelBase=zLevelBase)
+                comp += 1
+        finally:
+            f.close()
+    if dom is None:
+        raise McbratError("read_SSPTable: no single-scattering-property file given")
+    if calcRayl and not setup:  # :323-340
+        if commonD.rho is None or commonD.numConc is None:
+            raise McbratError("read_SSPTable: Error calculating rayleigh scattering.")
+        ext, ssa, pfi, table = calc_RayleighScattering(dom.lambda_um, commonD.rho[0, 0, :], commonD.numConc[0, 0, :])
+        dom.addOpticalComponent("Rayleigh Scattering", ext, ssa, pfi, table, zLevelBase=1)
+    dom.getOpticalPropertiesByComponent()
+    return dom
+
+
+def read_SolarSource(fileName, nLambda):
+    """read_SolarSource, src/emissionAndBroadBandWeights.f95:598-633 -> (sourceFunction, lambdas)."""
+    try:
+        f = netcdf_file(fileName, "r", mmap=False)
+    except (OSError, TypeError, ValueError):
+        raise McbratError("read_SolarSource: Can't open file " + str(fileName))
+    try:
+        if "Lambdas" not in f.dimensions or "Lambdas" not in f.variables or "SourceFunction" not in f.variables:
+            raise McbratError("read_SolarSource: %s doesn't look a solar source function file." % fileName)
+        if int(f.dimensions["Lambdas"]) != int(nLambda):
+            raise McbratError("read_SolarSource: %s dimension of solar source function does not match numLambdas from namelist." % fileName)
+        return np.array(f.variables["SourceFunction"][:], np.float64), np.array(f.variables["Lambdas"][:], np.float64)
+    finally:
+        f.close()
+
+
+def read_specResponseFunction(fileName, nLambda):
+    """read_specResponseFunction, src/emissionAndBroadBandWeights.f95:636-662."""
+    try:
+        f = netcdf_file(fileName, "r", mmap=False)
+    except (OSError, TypeError, ValueError):
+        raise McbratError("read_specResponseFunction: Can't open file " + str(fileName))
+    try:
+        if "Lambdas" not in f.dimensions or "SRF" not in f.variables:
+            raise McbratError("read_specResponseFunction: %s doesn't look a spectral response function file." % fileName)
+        if int(f.dimensions["Lambdas"]) != int(nLambda):
+            raise McbratError("read_specResponseFunction: %s dimension of spectral response function does not match numLambdas from namelist." % fileName)
+        return np.array(f.variables["SRF"][:], np.float64)
+    finally:
+        f.close()

@@ -309,6 +309,33 @@ static float surface_reflectance(const orc_problem *P, double xPos, double yPos)
   if (yi > nY - 1) yi = nY - 1;
   return P->surfReflectance[(size_t)(xi - 1) + (size_t)(nX - 1) * (yi - 1)];
 }
+/* getFrequencyDistrNEW, src/emissionAndBroadBandWeights.f95:552-572: one uniform per photon, findCDFIndex against the
+ * power CDF.  MT mode: the uniforms are the next numbers of the stream (the reference).  Philox mode: draw d is
+ * element d % 4 of block (0xFFFFFFFF, 0, d / 4) under the key, d counted from firstDraw (what the HIP kernel does). */
+void orc_frequency_distribution(orc_rng *r, uint64_t firstDraw, int numLambda, const double *cdf, int64_t totalPhotons,
+                                int64_t *distribution) {
+  for (int i = 0; i < numLambda; i++) distribution[i] = 0;
+  uint32_t buf[4];
+  uint64_t cached = ~(uint64_t)0;
+  for (int64_t n = 0; n < totalPhotons; n++) {
+    float RN;
+    if (r->mode == 0) RN = orc_random_real(r);
+    else {
+      const uint64_t d = firstDraw + (uint64_t)n, blk = d / 4;
+      if (blk != cached) {
+        uint32_t ctr[4] = {0xFFFFFFFFu, 0u, (uint32_t)blk, (uint32_t)(blk >> 32)};
+        uint32_t key[2] = {(uint32_t)r->seed, (uint32_t)(r->seed >> 32)};
+        orc_philox4x32_10(ctr, key, buf);
+        cached = blk;
+      }
+      RN = (float)buf[d % 4] * 2.3283064365386963e-10f;
+    }
+    int i = orc_find_cdf_index(RN, cdf, numLambda);
+    if (i > numLambda) i = numLambda;
+    distribution[i - 1]++;
+  }
+}
+
 /* exported for the pin against the reference's own computeSurfaceReflectance (tests/golden/ref_surface.json) */
 float orc_surface_reflectance(const orc_problem *P, double xPos, double yPos) { return surface_reflectance(P, xPos, yPos); }
 int orc_find_cdf_index(float vf, const double *t, int n) { /* :317-348 */

@@ -110,6 +110,7 @@ void orc_legendre(int maxL, int nmu, const float *mus, float *out);/* :187-205; 
 int  orc_find_index_real(float v, const float *t, int n, int firstGuess);     /* :417-470 (0 = no guess) */
 int  orc_find_index_double(double v, const double *t, int n, int firstGuess); /* :207-260 */
 int  orc_find_index_mixed(float v, const double *t, int n, int firstGuess);   /* :262-315 */
+void orc_frequency_distribution(orc_rng *r, uint64_t firstDraw, int numLambda, const double *cdf, int64_t totalPhotons, int64_t *distribution); /* emissionAndBroadBandWeights.f95:552-572 */
 float orc_surface_reflectance(const orc_problem *P, double xPos, double yPos); /* surfaceProperties.f95:119-147 */
 int  orc_find_cdf_index(float v, const double *t, int n);                     /* :317-348 */
 

@@ -108,6 +108,7 @@ def lib():
         L.orc_find_cdf_index.argtypes = [C.c_float, C.c_void_p, C.c_int]
         L.orc_emission_weighting.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_double] * 4 + [C.c_void_p] * 3
         L.orc_philox_init.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.orc_frequency_distribution.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.orc_surface_reflectance.restype = C.c_float
         L.orc_surface_reflectance.argtypes = [C.c_void_p, C.c_double, C.c_double]
         _LIB = L
@@ -141,6 +142,14 @@ def philox_rng(seed, first_photon=0):
 def random_reals(r, n):
     L = lib()
     return np.array([L.orc_random_real(C.byref(r)) for _ in range(n)], dtype=np.float32)
+
+
+def frequency_distribution(rng, cdf, total_photons, first_draw=0):
+    """getFrequencyDistr (src/emissionAndBroadBandWeights.f95:552-572): photons per wavelength."""
+    cdf = np.ascontiguousarray(cdf, np.float64)
+    out = np.zeros(cdf.size, np.int64)
+    lib().orc_frequency_distribution(C.byref(rng), int(first_draw), int(cdf.size), _p(cdf), int(total_photons), _p(out))
+    return out
 
 
 def philox4x32_10(ctr, key):

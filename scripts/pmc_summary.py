@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"),
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            short = "trace_kernel" if "trace_kernel" in k else k.split("(")[0][-40:]
+            short = "trace_kernel" if ("trace_kernel" in k or "trace_block_kernel" in k) and "true>(" not in k.split("DevParams")[0][-12:] else k.split("(")[0][-40:]
             acc[short][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
 out = {}
 for kern, ctrs in acc.items():
