@@ -64,6 +64,7 @@ struct mcbrat_ctx {
   uint16_t *dBlockOf = nullptr;
   int nBlocks = 0;
   int crossThreshold = 8;      // MCBRAT_CROSS_THRESHOLD
+  int jumpThreshold = 8;       // MCBRAT_JUMP_THRESHOLD
   float *dExtB = nullptr, *dCumB = nullptr, *dSsaB = nullptr, *dBgExt = nullptr, *dBgCum = nullptr, *dBgSsa = nullptr;
   uint16_t *dPfiB = nullptr, *dBgPfi = nullptr;
   int nbx = 0, nby = 0, nbz = 0;
@@ -109,7 +110,8 @@ struct mcbrat_ctx {
   // tuning / measurement
   int blocksPerCU = 0;  // 0: from the occupancy query
   int eventThreshold = 16;     // measured optimum 16 (step cloud) .. 32 (128x128x64); see DESIGN.md
-  int launchThreshold = 8, surfaceThreshold = 8;
+  int launchThreshold = 8, surfaceThreshold = 12;  // (exits -- top and surface -- queue together: 12-16 measured best)
+  bool surfaceThresholdSet = false;  // by the caller: the block walk otherwise uses its own measured default
   bool autoTune = true;        // pick eventThreshold by timing short trial launches (once per domain/source)
   bool tuned = false;
   int maxBatchesInFlight = 0;  // 0: bounded by memory
@@ -465,6 +467,7 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.limitContrib = c->limitContrib; p.maxContrib = c->maxContrib;
   p.nBlocks = c->nBlocks; p.blockRec = reinterpret_cast<const uint4 *>(c->dBlockRec); p.blockOf = c->dBlockOf;
   p.crossThreshold = std::max(1, std::min(64, c->crossThreshold));
+  p.jumpThreshold = std::max(1, std::min(64, c->jumpThreshold));
   p.counter = c->L().dCounter;
   p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
   p.launchThreshold = std::max(1, std::min(64, c->launchThreshold));
@@ -694,6 +697,7 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (const char *e = getenv("MCBRAT_REGULAR_WALK")) c->regularWalk = atoi(e);
   if (const char *e = getenv("MCBRAT_LAYER_SKIP")) c->layerSkip = atoi(e);
   if (const char *e = getenv("MCBRAT_BLOCK_WALK")) c->blockWalk = atoi(e);
+  if (const char *e = getenv("MCBRAT_JUMP_THRESHOLD")) c->jumpThreshold = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_CROSS_THRESHOLD")) c->crossThreshold = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_RAY_DEFER")) c->rayDefer = atoi(e);
   if (const char *e = getenv("MCBRAT_RAY_SHORT")) c->rayShort = std::max(1, atoi(e));
@@ -1086,7 +1090,7 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   if (blockSize == 0 || blockSize == 256 || blockSize == 512 || blockSize == 768) c->blockSize = blockSize;
   else if (blockSize > 0) return fail(c, "set_tuning: blockSize must be 0, 256, 512 or 768");
   if (launchThreshold > 0) c->launchThreshold = launchThreshold;
-  if (surfaceThreshold > 0) c->surfaceThreshold = surfaceThreshold;
+  if (surfaceThreshold > 0) { c->surfaceThreshold = surfaceThreshold; c->surfaceThresholdSet = true; }
   if (brickLayout >= 0 && brickLayout <= 2) { if (brickLayout != c->brickMode) c->tuned = false; c->brickMode = brickLayout; }
   return 0;
 }

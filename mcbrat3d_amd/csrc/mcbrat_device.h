@@ -102,7 +102,8 @@ struct DevParams {
   unsigned long long unitsPerBatch;  // ... and how many of them a batch is cut into
   int eventThreshold;             // process events when fewer than this many lanes are walking
   int launchThreshold;            // idle lanes queued before new photons are launched
-  int surfaceThreshold;           // lanes queued before surface reflections are served
+  int surfaceThreshold;           // lanes queued before exits (top / surface) are served
+  int jumpThreshold;              // lanes queued before transitions of the layer-skipping walk are served
   // debug / measurement
   mcbrat_fate *fates;             // non-null: record per-photon fate (index = photon index)
   unsigned long long *counters;   // non-null: event counters

@@ -1,0 +1,14 @@
+#!/bin/bash
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/r02c9
+mkdir -p $OUT
+cd $ROOT
+for c in landsat radar; do
+python scripts/ab_compare.py $c 32 >> $OUT/ab.log 2>&1
+MCBRAT_LIB=$ROOT/ab/libmcbrat_spec.so python scripts/ab_compare.py $c 32 >> $OUT/ab.log 2>&1
+MCBRAT_LIB=$ROOT/ab/libmcbrat_spec.so python scripts/ab_compare.py $c 24 >> $OUT/ab.log 2>&1
+MCBRAT_LIB=$ROOT/ab/libmcbrat_spec.so python scripts/ab_compare.py $c 40 >> $OUT/ab.log 2>&1
+done
+cat $OUT/ab.log | grep lib=
+echo finished
