@@ -63,7 +63,9 @@ __host__ __device__ inline BlockLds block_lds_layout(int nx, int ny, int nz, int
   return L;
 }
 
-template <int BLOCK, bool TBL_LDS, bool DEBUG>
+// EMIT: the thermal-emission source (newPhotonStream_BBEmission); its launch code and parameters are compiled out of the
+// solar instantiations (registers and instruction cache for the loop that matters).
+template <int BLOCK, bool TBL_LDS, bool DEBUG, bool EMIT>
 __global__ void __launch_bounds__(BLOCK, BLOCK > 512 ? BLOCK / 128 : MCBRAT_MIN_WAVES_PER_SIMD)
 trace_block_kernel(const DevParams p) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -283,7 +285,7 @@ trace_block_kernel(const DevParams p) {
             uint32_t r[4];
             philox4x32_10(0u, 0u, idLo, idHi, p.seedLo, p.seedHi, r);
             double lx, ly, lz;  // fractional launch position in [0,1]
-            if (p.srcKind == 0) {  // newPhotonStream_Directional, monteCarloIllumination.f95:88-96
+            if (!EMIT) {  // newPhotonStream_Directional, monteCarloIllumination.f95:88-96
               lx = (double)u01(r[0]);
               ly = (double)u01(r[1]);
               lz = 0.0;
@@ -341,7 +343,7 @@ trace_block_kernel(const DevParams p) {
               ix = find_cell(s_edge, p.nx, px);
               iy = find_cell(s_edge + offY, p.ny, py);
             }
-            if (p.srcKind == 0) {
+            if (!EMIT) {
               pz = p.zLaunch; iz = p.izLaunch;
             } else if (p.zRegular) {  // :485-486
               pz = p.z0 + lz * (p.zMax - p.z0);
@@ -352,7 +354,7 @@ trace_block_kernel(const DevParams p) {
               iz = min((int)fl, p.nz - 1);
               pz = s_edge[offZ + iz] + (t - fl) * (s_edge[offZ + iz + 1] - s_edge[offZ + iz]);
             }
-            if (p.lwFlag && pz > 0.0)  // :504-508 emission counts as negative absorption
+            if (EMIT && p.lwFlag && pz > 0.0)  // :504-508 emission counts as negative absorption
               atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + 2 * ncol + (ix + p.nx * (iy + p.ny * iz))), to_fixed(-1.0));
             needLeg = true;
           } else {

@@ -1,4 +1,12 @@
-"""Summarises rocprofv3 --pmc CSVs: per-kernel mean of every counter over dispatches of trace_kernel."""
+"""Summarises rocprofv3 --pmc CSVs: per-launch mean of every counter over the dispatches of the tracing kernel
+(trace_kernel / trace_block_kernel, the non-instrumented instantiation), plus the derived figures bench.py's
+`roofline.valu` object and `roofline.traffic` are built from.
+
+    python scripts/pmc_summary.py <dir with pass*/ subdirectories> [workload photons_per_launch fetch_correction]
+
+With the three extra arguments the derived record is also merged into profiles/pmc_shipped.json under `workload`.
+fetch_correction: 2.0 where the kernel's HBM-side reads are wide coalesced streams (the guide's gfx950 correction:
+FETCH_SIZE counts 64 B per 128-B request), 1.0 where they are 4-byte gathers (uncalibrated there; raw)."""
 import csv
 import glob
 import json
@@ -12,7 +20,9 @@ for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"),
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            short = "trace_kernel" if ("trace_kernel" in k or "trace_block_kernel" in k) and "true>(" not in k.split("DevParams")[0][-12:] else k.split("(")[0][-40:]
+            tracing = ("trace_kernel" in k or "trace_block_kernel" in k)
+            debug = tracing and k.split("(mcbrat::DevParams")[0].rstrip(">").rstrip().endswith("true") and "trace_block_kernel" in k
+            short = "trace_kernel" if tracing and not debug else k.split("(")[0][-40:]
             acc[short][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
 out = {}
 for kern, ctrs in acc.items():
@@ -28,13 +38,30 @@ print(json.dumps({k: v for k, v in t.items() if not k.startswith("_")}, indent=1
 with open(os.path.join(root, "summary.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 
-# HBM-side traffic per launch of the tracing kernel, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
-# WRITE_SIZE are in KB, from separate passes; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a
-# wide coalesced stream (x2); this kernel's reads are 4-8 B gathers, for which the factor is
-# uncalibrated, so both raw and corrected values are kept.
-if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
-    traffic = {"fetch_kb_raw": t["FETCH_SIZE"], "write_kb": t["WRITE_SIZE"],
-               "hbm_bytes_per_launch": (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0,
-               "hbm_bytes_per_launch_uncorrected": (t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0}
-    with open(os.path.join(root, "traffic.json"), "w") as fh:
-        json.dump(traffic, fh, indent=1)
+if len(sys.argv) >= 5 and t:
+    workload, ppl, corr = sys.argv[2], int(float(sys.argv[3])), float(sys.argv[4])
+    g = lambda k: t.get(k)  # noqa: E731
+    rec = {"photons_per_launch": ppl,
+           "valu_insts_per_launch": g("SQ_INSTS_VALU"), "salu_insts_per_launch": g("SQ_INSTS_SALU"),
+           "lds_insts_per_launch": g("SQ_INSTS_LDS"), "waves_per_launch": g("SQ_WAVES"),
+           # lanes that do work per VALU instruction: thread-cycles / (64 x wave-level active cycles)
+           "lane_occupancy": g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU")) if g("SQ_ACTIVE_INST_VALU") else None,
+           # wave lifetime: issuing / parked in s_waitcnt / ready but not issued (the three are disjoint and add up to ~1)
+           "wave_time_issuing": g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES") if g("SQ_WAVE_CYCLES") else None,
+           "wave_time_waiting": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES") if g("SQ_WAVE_CYCLES") else None,
+           "wave_time_issue_stall": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES") if g("SQ_WAVE_CYCLES") else None,
+           "lds_bank_conflict_ratio": g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") else None,
+           "l2_requests_per_launch": g("TCC_REQ_sum"), "l2_hit_rate": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")) if g("TCC_HIT_sum") is not None else None,
+           "l2_misses_per_launch": g("TCC_MISS_sum"), "global_atomics_per_launch": g("TCC_ATOMIC_sum"),
+           "fetch_kb_raw": g("FETCH_SIZE"), "write_kb": g("WRITE_SIZE"), "fetch_correction": corr,
+           "hbm_bytes_per_launch": (corr * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None else None,
+           "source": "rocprofv3 --pmc, separate passes (scripts/pmc_profile.sh), %s; launch = %d photons, fixed event threshold" % (os.path.basename(os.path.normpath(root)), ppl)}
+    shipped = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_shipped.json")
+    cur = {}
+    if os.path.exists(shipped):
+        with open(shipped) as fh:
+            cur = json.load(fh)
+    cur[workload] = rec
+    with open(shipped, "w") as fh:
+        json.dump(cur, fh, indent=1)
+    print("merged", workload, "into", shipped)
