@@ -356,6 +356,10 @@ def main():
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # BENCH_FORCE_DIST outside a launcher: a one-rank job
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         # RCCL prints a version banner on stdout when its communicator comes up; the contract is ONE JSON line there,
         # so file descriptor 1 points at stderr until the first collective is through
