@@ -353,6 +353,11 @@ def main():
         a.no_cpu_baseline = True  # the CPU baseline (and the parity check against it) belongs to the N = 1 line
     import torch
     dist = None
+    # BENCH_REHEARSE=1: every rank on cuda:0 and gloo instead of RCCL (which refuses two ranks on one device) -- the
+    # whole N > 1 code path of this file on a one-GPU box; the numbers it prints are not a measurement
+    rehearse = bool(os.environ.get("BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -367,7 +372,10 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             warm = torch.zeros(1, device=torch.device("cuda", local_rank))
             dist.all_reduce(warm)
             torch.cuda.synchronize()
@@ -474,6 +482,7 @@ def main():
                        % (a.workload, nx, ny, nz, per_step, nb, ppb, w["mu0"]),
                        "photons_per_step_per_gpu": per_step, "parallelism": "photon batches sharded over %d GPU(s)" % world,
                        "world_size": dist.get_world_size() if dist is not None else 1,
+                       **({"rehearsal": "gloo, all ranks on cuda:0 -- not a measurement"} if rehearse else {}),
                        "photons_in_reduced_moments_last_step": reduced_photons,
                        "pipelined_steps": bool(a.pipeline), "event_threshold": integ.eventThreshold(),
                        "walk": integ.walkMode()},

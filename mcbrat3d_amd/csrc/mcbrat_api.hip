@@ -1292,8 +1292,8 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     {
       unsigned long long st[16];
       HIP_OK(c, hipMemcpy(st, c->dEventCounters + 16, sizeof(st), hipMemcpyDeviceToHost));
-      const char *names[9] = {"launch", "top", "collideA(pos,optics,absorb,roulette)", "collideB(angle,cos)", "collideC(next_direct)",
-                              "surface", "leg", "walk", "phase-head"};
+      const char *names[9] = {"launch", "(unused)", "collideA(pos,optics,absorb,roulette)", "collideB(angle,cos)", "collideC(next_direct)",
+                              "exits(top,surface)", "leg", "walk", "phase-head(jump,column look-up)"};
       double tot = 0;
       for (int i = 0; i < 9; i++) tot += (double)st[i];
       for (int i = 0; i < 9; i++) fprintf(stderr, "stamp %-40s %14llu  %5.1f %%\n", names[i], st[i], 100.0 * (double)st[i] / tot);
