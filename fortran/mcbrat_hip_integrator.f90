@@ -27,7 +27,7 @@ module mcbrat_hip_integrator
             resetMoments, getMoments, momentsLength, lastMessage, &
             inverseTableLegendre, lastTraceMilliseconds, setAsynchronous, synchronize, &
             specifyIntensity, setForwardTable, reportIntensity, forwardTableLegendre, &
-            setSurfaceDescription
+            setSurfaceDescription, setWalkOptions, getFrequencyDistr, shareMoments
 
   interface
     function mcbrat_create(device) bind(C, name="mcbrat_create") result(ctx)
@@ -174,6 +174,32 @@ module mcbrat_hip_integrator
       import :: c_ptr, c_float
       type(c_ptr), value :: ctx
       real(c_float) :: ms
+    end function
+    function mcbrat_set_walk_options(ctx, layerSkip, blockWalk) bind(C, name="mcbrat_set_walk_options") result(rc)
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: layerSkip, blockWalk
+      integer(c_int) :: rc
+    end function
+    function mcbrat_frequency_distribution(ctx, seed, firstDraw, numLambda, cdf, totalPhotons, distribution) &
+        bind(C, name="mcbrat_frequency_distribution") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: seed, firstDraw, totalPhotons
+      integer(c_int32_t), value :: numLambda
+      real(c_double), intent(in) :: cdf(*)
+      integer(c_int64_t), intent(out) :: distribution(*)
+      integer(c_int) :: rc
+    end function
+    function mcbrat_moments_device_pointer(ctx) bind(C, name="mcbrat_moments_device_pointer") result(p)
+      import :: c_ptr
+      type(c_ptr), value :: ctx
+      type(c_ptr) :: p
+    end function
+    function mcbrat_bind_moments(ctx, deviceBuffer) bind(C, name="mcbrat_bind_moments") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, deviceBuffer
+      integer(c_int) :: rc
     end function
     function mcbrat_inverse_table_legendre(nCoef, coef, nSteps, table) bind(C, name="mcbrat_inverse_table_legendre") result(rc)
       import :: c_int, c_int32_t, c_float
@@ -397,6 +423,31 @@ contains
     integer, intent(out) :: ierr
     ierr = mcbrat_synchronize(this%ctx)
   end subroutine synchronize
+  !------------------------------------------------------------------------------------------
+  ! layerSkip / blockWalk: .false. restores the reference's face-by-face walk (include/mcbrat.h)
+  subroutine setWalkOptions(this, layerSkip, blockWalk, ierr)
+    type(integrator), intent(inout) :: this
+    logical, intent(in) :: layerSkip, blockWalk
+    integer, intent(out) :: ierr
+    ierr = mcbrat_set_walk_options(this%ctx, merge(1_c_int32_t, 0_c_int32_t, layerSkip), merge(1_c_int32_t, 0_c_int32_t, blockWalk))
+  end subroutine setWalkOptions
+  ! getFrequencyDistr (src/emissionAndBroadBandWeights.f95:552-572) with the draws made and counted on the device
+  subroutine getFrequencyDistr(this, CDF, totalPhotons, iseed, distribution, ierr)
+    type(integrator), intent(inout) :: this
+    real(8), dimension(:), intent(in) :: CDF
+    integer(8), intent(in) :: totalPhotons
+    integer, intent(in) :: iseed
+    integer(8), dimension(:), intent(out) :: distribution
+    integer, intent(out) :: ierr
+    ierr = mcbrat_frequency_distribution(this%ctx, int(iseed, c_int64_t), 0_c_int64_t, int(size(CDF), c_int32_t), CDF, &
+                                         int(totalPhotons, c_int64_t), distribution)
+  end subroutine getFrequencyDistr
+  ! spectrally integrated runs: `this` (another wavelength's integrator on the same grid) accumulates into `first`'s moments
+  subroutine shareMoments(this, first, ierr)
+    type(integrator), intent(inout) :: this, first
+    integer, intent(out) :: ierr
+    ierr = mcbrat_bind_moments(this%ctx, mcbrat_moments_device_pointer(first%ctx))
+  end subroutine shareMoments
   real function lastTraceMilliseconds(this)
     type(integrator), intent(in) :: this
     lastTraceMilliseconds = mcbrat_last_trace_ms(this%ctx)
