@@ -511,15 +511,15 @@ size_t plan_launch_lds(const mcbrat_ctx *c, const LaunchPlan &L) {
          (L.tblLds ? sizeof(float) * (size_t)c->tblTotalFloats : 0);
 }
 
-template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN, bool EMIT>
+template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN, bool EMIT, int SPEC = 0>
 int launch_trace_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   if (lds > c->ldsPerCU) return fail(c, "computeRadiativeTransfer: the grid's edge and layer tables do not fit the LDS of a compute unit.");
   if (lds > kLdsBudget)  // (very tall grids: the per-layer tables alone can pass the default limit of a workgroup)
-    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT>),
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int perCU = c->blocksPerCU;
   if (perCU <= 0) {
-    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT>, BLOCK, lds));
+    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC>, BLOCK, lds));
     perCU = std::max(1, std::min(perCU, 8));
   }
   unsigned long long blocks = (unsigned long long)perCU * c->numCUs;
@@ -535,7 +535,7 @@ int launch_trace_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
     blocks = std::min(blocks, (p.total + BLOCK - 1) / BLOCK);
   }
   const unsigned grid = (unsigned)std::max<unsigned long long>(1, blocks);
-  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT>), dim3(grid), dim3(BLOCK), lds, c->L().stream, p);
+  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC>), dim3(grid), dim3(BLOCK), lds, c->L().stream, p);
   HIP_OK(c, hipGetLastError());
   return 0;
 }
@@ -543,6 +543,17 @@ int launch_trace_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
 template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN = false>
 int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   // (the source kind is a template parameter: the emission launch code costs the solar instantiations registers)
+  if constexpr (BLOCK == 256 && PRIV == 0 && !BRICK && !DBG && !INTEN) {
+    // the large flux runs: dense grid in global memory, collision records (nc <= 2), layer-skipping walk, albedo
+    // surface -- with the walk's spacing flags decided at compile time too (SPEC, mcbrat_kernels.hip)
+    if (p.rec != nullptr && p.layerSkip && p.surfNumX == 0 && p.xyRegularWalk == p.zRegularWalk) {
+      if (p.xyRegularWalk)
+        return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 2>(c, p, lds, nBatches)
+                               : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 2>(c, p, lds, nBatches);
+      return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 1>(c, p, lds, nBatches)
+                             : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 1>(c, p, lds, nBatches);
+    }
+  }
   return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false>(c, p, lds, nBatches)
                          : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true>(c, p, lds, nBatches);
 }
@@ -592,9 +603,9 @@ bool block_walk_applies(const mcbrat_ctx *c, const LaunchPlan &L) {
   return (size_t)c->nBlocks * 4 <= nvox || c->blockWalk == 2;  // (2: forced, for tests of heterogeneous media)
 }
 
-template <int BLOCK, bool TBL, bool DBG, bool EMIT>
-int launch_block_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
-  auto kernel = trace_block_kernel<BLOCK, TBL, DBG, EMIT>;
+template <int BLOCK, bool TBL, bool DBG, bool EMIT, int SIMPLE>
+int launch_block_s(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
+  auto kernel = trace_block_kernel<BLOCK, TBL, DBG, EMIT, SIMPLE>;
   if (lds > c->ldsPerCU) return fail(c, "computeRadiativeTransfer: the block-walk tables do not fit the LDS of a compute unit.");
   if (lds > kLdsBudget)
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -612,6 +623,14 @@ int launch_block_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<unsigned long long>(1, blocks)), dim3(BLOCK), lds, c->L().stream, p);
   HIP_OK(c, hipGetLastError());
   return 0;
+}
+
+template <int BLOCK, bool TBL, bool DBG, bool EMIT>
+int launch_block_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
+  // equally spaced axes, one component, no surface description: the instantiation with those decided at compile time
+  const bool simple = c->xyRegular && c->zRegular && c->nc == 1 && c->surfNumX == 0;
+  if (simple && c->ny == 1 && !DBG) return launch_block_s<BLOCK, TBL, DBG, EMIT, 2>(c, p, lds, nBatches);  // an x-z problem
+  return simple ? launch_block_s<BLOCK, TBL, DBG, EMIT, 1>(c, p, lds, nBatches) : launch_block_s<BLOCK, TBL, DBG, EMIT, 0>(c, p, lds, nBatches);
 }
 
 template <int BLOCK, bool TBL, bool DBG>

@@ -65,9 +65,21 @@ __host__ __device__ inline BlockLds block_lds_layout(int nx, int ny, int nz, int
 
 // EMIT: the thermal-emission source (newPhotonStream_BBEmission); its launch code and parameters are compiled out of the
 // solar instantiations (registers and instruction cache for the loop that matters).
-template <int BLOCK, bool TBL_LDS, bool DEBUG, bool EMIT>
+// SIMPLE: equally spaced axes (as the reference's own test says, new_Integrator :163-181), one component, the domain's
+// Lambertian albedo -- the I3RC step cloud, plane-parallel and homogeneous domains.  What the general kernel decides
+// at run time from wave-uniform parameters (bisection or division, how many components, surface description or albedo)
+// is decided at compile time here: the branches and the scalar registers they keep alive leave the loop.
+// SIMPLE = 2: as 1, and the domain is one cell wide in y (the I3RC step cloud and the plane-parallel cases are x-z
+// problems): with a uniform surface nothing depends on the y position, so the y part of the leg origin, of the face
+// distances and of the cell look-ups is compiled out (the direction keeps its y component; the instrumented
+// instantiation keeps y, it counts the periodic y faces a leg crosses as the reference does).
+template <int BLOCK, bool TBL_LDS, bool DEBUG, bool EMIT, int SIMPLE>
 __global__ void __launch_bounds__(BLOCK, BLOCK > 512 ? BLOCK / 128 : MCBRAT_MIN_WAVES_PER_SIMD)
 trace_block_kernel(const DevParams p) {
+  constexpr bool NOY = SIMPLE == 2 && !DEBUG;
+  const bool xyRegular = SIMPLE != 0 ? true : p.xyRegular != 0;
+  const bool zRegular = SIMPLE != 0 ? true : p.zRegular != 0;
+  const int nc = SIMPLE != 0 ? 1 : p.nc;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   // LDS map: [edges x|y|z (double)] [private tally slab (i64)] [unit cursor] [block records (uint4)] [extinction]
   //          [ssa] [cum] [phase index (u16)] [block of each cell (u16)] [tables (float), TBL_LDS]
@@ -76,7 +88,7 @@ trace_block_kernel(const DevParams p) {
   const int ncol = p.nx * p.ny;
   const int nvox = ncol * p.nz;
   const int slabLen = (int)p.slabStride;
-  const BlockLds lay = block_lds_layout(p.nx, p.ny, p.nz, p.nc, (size_t)slabLen, p.nBlocks, TBL_LDS ? (size_t)p.tblTotalFloats : 0);
+  const BlockLds lay = block_lds_layout(p.nx, p.ny, p.nz, nc, (size_t)slabLen, p.nBlocks, TBL_LDS ? (size_t)p.tblTotalFloats : 0);
   long long *s_slab = reinterpret_cast<long long *>(smem_raw + lay.slab);
   unsigned *s_cursor = reinterpret_cast<unsigned *>(smem_raw + lay.cursor);
   uint4 *s_blockRec = reinterpret_cast<uint4 *>(smem_raw + lay.rec);
@@ -100,9 +112,9 @@ trace_block_kernel(const DevParams p) {
   if (threadIdx.x == 0) s_cursor[0] = 0;
   for (int i = threadIdx.x; i < p.nBlocks; i += BLOCK) s_blockRec[i] = p.blockRec[i];
   for (int i = threadIdx.x; i < nvox; i += BLOCK) { s_ext[i] = p.ext[i]; s_blockOf[i] = p.blockOf[i]; }
-  for (int i = threadIdx.x; i < p.nc * nvox; i += BLOCK) { s_ssa[i] = p.ssa[i]; s_pfi[i] = p.pfi[i]; }
-  if (p.nc > 1)
-    for (int i = threadIdx.x; i < p.nc * nvox; i += BLOCK) s_cum[i] = p.cum[i];
+  for (int i = threadIdx.x; i < nc * nvox; i += BLOCK) { s_ssa[i] = p.ssa[i]; s_pfi[i] = p.pfi[i]; }
+  if (nc > 1)
+    for (int i = threadIdx.x; i < nc * nvox; i += BLOCK) s_cum[i] = p.cum[i];
   __syncthreads();
   const float *__restrict__ tbl = TBL_LDS ? s_tbl : p.tables;
   const int offY = p.nx + 1, offZ = p.nx + p.ny + 2;  // edge table offsets
@@ -153,18 +165,19 @@ trace_block_kernel(const DevParams p) {
       px -= shift; xw -= shift;
       if (DEBUG) dbgX -= (long long)rint(shift * p.invLx) * p.nx;
     }
-    if (p.xyRegular) return min(max((int)((xw - p.x0) * p.invDX), 0), p.nx - 1);
+    if (xyRegular) return min(max((int)((xw - p.x0) * p.invDX), 0), p.nx - 1);
     double o = 0.0;
     return locate_periodic(s_edge, p.nx, p.x0, p.Lx, p.invLx, p.invCellX, p.xyNearUniform != 0, o, xw);
   };
   auto locY = [&](double yw, bool canLeave, bool force = false) {
+    if (NOY) return 0;
     if (p.ny == 1 && !force) return 0;
     if (canLeave) {
       const double shift = floor((yw - p.y0) * p.invLy) * p.Ly;
       py -= shift; yw -= shift;
       if (DEBUG) dbgY -= (long long)rint(shift * p.invLy) * p.ny;
     }
-    if (p.xyRegular) return min(max((int)((yw - p.y0) * p.invDY), 0), p.ny - 1);
+    if (xyRegular) return min(max((int)((yw - p.y0) * p.invDY), 0), p.ny - 1);
     double o = 0.0;
     return locate_periodic(s_edge + offY, p.ny, p.y0, p.Ly, p.invLy, p.invCellY, p.xyNearUniform != 0, o, yw);
   };
@@ -174,12 +187,12 @@ trace_block_kernel(const DevParams p) {
     const uint4 rec = s_blockRec[s_blockOf[cell]];
     extCur = s_ext[cell];
     fx = dx >= 0.0f ? (int)(rec.x >> 16) : (int)(rec.x & 0xffffu);
-    fy = dy >= 0.0f ? (int)(rec.y >> 16) : (int)(rec.y & 0xffffu);
+    if (!NOY) fy = dy >= 0.0f ? (int)(rec.y >> 16) : (int)(rec.y & 0xffffu);
     fz = dz >= 0.0f ? (int)(rec.z >> 16) : (int)(rec.z & 0xffffu);
     // a block that spans a whole periodic axis has no face on it (the lane's position runs through the images)
     spans |= rec.w;  // (a leg that has been through such a block may have left the principal image since its last fold)
     tnx = ((rec.w & 1u) || ivx == 0.0f) ? FLT_MAX : (float)(s_edge[fx] - px) * ivx;
-    tny = ((rec.w & 2u) || ivy == 0.0f) ? FLT_MAX : (float)(s_edge[offY + fy] - py) * ivy;
+    tny = (NOY || (rec.w & 2u) || ivy == 0.0f) ? FLT_MAX : (float)(s_edge[offY + fy] - py) * ivy;
     tnz = ivz == 0.0f ? FLT_MAX : (float)(s_edge[offZ + fz] - pz) * ivz;
   };
 
@@ -217,7 +230,8 @@ trace_block_kernel(const DevParams p) {
         {
           const double xw = px + (double)tcur * (double)dx, yw = py + (double)tcur * (double)dy;  // where the leg met the face (:1801-1812)
           if (DEBUG) countCrossings(xw, yw, top ? p.nz : -1);
-          px = xw; py = yw;
+          px = xw;
+          if (!NOY) py = yw;
           ix = locX(xw, true, true);  // (always folded here: the surface description takes the position itself)
           iy = locY(yw, true, true);
         }
@@ -243,7 +257,7 @@ trace_block_kernel(const DevParams p) {
             }
           }
           const float wIn = w;
-          if (p.surfNumX > 0) w = w * surface_reflectance(p, px, py);  // useSurfaceBDRF :667-670
+          if (SIMPLE == 0 && p.surfNumX > 0) w = w * surface_reflectance(p, px, py);  // useSurfaceBDRF :667-670
           else w = (float)((double)w * (double)p.albedo);              // :673
           if (w <= FLT_MIN) {
             if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{1, ix + 1, iy + 1, 1, nScat, nLegs, wIn};
@@ -335,17 +349,17 @@ trace_block_kernel(const DevParams p) {
             }
             w = 1.0f;
             px = p.x0 + lx * (p.xMax - p.x0);  // :480-482
-            py = p.y0 + ly * (p.yMax - p.y0);
-            if (p.xyRegular) {  // findXYIndicies :1558-1562
+            if (!NOY) py = p.y0 + ly * (p.yMax - p.y0);
+            if (xyRegular) {  // findXYIndicies :1558-1562
               ix = min((int)((px - p.x0) * p.invDX), p.nx - 1);
-              iy = min((int)((py - p.y0) * p.invDY), p.ny - 1);
+              iy = NOY ? 0 : min((int)((py - p.y0) * p.invDY), p.ny - 1);
             } else {
               ix = find_cell(s_edge, p.nx, px);
-              iy = find_cell(s_edge + offY, p.ny, py);
+              iy = NOY ? 0 : find_cell(s_edge + offY, p.ny, py);
             }
             if (!EMIT) {
               pz = p.zLaunch; iz = p.izLaunch;
-            } else if (p.zRegular) {  // :485-486
+            } else if (zRegular) {  // :485-486
               pz = p.z0 + lz * (p.zMax - p.z0);
               iz = min((int)((pz - p.z0) / ((p.zMax - p.z0) / (double)p.nz)), p.nz - 1);
             } else {  // :491-493 layer-index fraction
@@ -367,13 +381,13 @@ trace_block_kernel(const DevParams p) {
         {  // opticalProperties.f95:1729-1738: the point inside the block where tau is used up
           const double s = (double)(tcur + div_fast(tau - acc, extCur));
           px = px + s * (double)dx;
-          py = py + s * (double)dy;
+          if (!NOY) py = py + s * (double)dy;
           pz = pz + s * (double)dz;
         }
         // its cell, from the position (the periodic fold moves the position into the domain)
         {
           const double xw = px, yw = py;
-          iz = locate_z(s_edge + offZ, p.nz, p.zRegular != 0, p.z0, invDz, pz);
+          iz = locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, pz);
           if (DEBUG) countCrossings(xw, yw, iz);
           ix = locX(xw, (spans & 1u) != 0);
           iy = locY(yw, (spans & 2u) != 0);
@@ -382,8 +396,8 @@ trace_block_kernel(const DevParams p) {
         nScat++;
         if (DEBUG) cColl++;
         int c = 0;  // component pick :759-760 (findIndex over [0, cumExt(:)]), uniform = slot Z of the leg's block
-        if (p.nc > 1) {
-          for (int k = 0; k < p.nc - 1; k++)
+        if (nc > 1) {
+          for (int k = 0; k < nc - 1; k++)
             if (uZ >= s_cum[k * nvox + cell]) c = k + 1;
         }
         const float ssa = s_ssa[c * nvox + cell];
@@ -462,7 +476,7 @@ trace_block_kernel(const DevParams p) {
         acc = 0.0f; tcur = 0.0f;
         // opticalProperties.f95:1705-1712: huge step for a zero cosine
         ivx = fabsf(dx) >= 2.0f * FLT_MIN ? rcp_fast(dx) : 0.0f;
-        ivy = fabsf(dy) >= 2.0f * FLT_MIN ? rcp_fast(dy) : 0.0f;
+        ivy = (!NOY && fabsf(dy) >= 2.0f * FLT_MIN) ? rcp_fast(dy) : 0.0f;
         ivz = fabsf(dz) >= 2.0f * FLT_MIN ? rcp_fast(dz) : 0.0f;
         spans = 0;  // (the leg starts inside the domain: its origin was folded where it was located)
         enterBlock(ix, iy, iz);
@@ -470,7 +484,7 @@ trace_block_kernel(const DevParams p) {
       }
       // ---- block crossings: the cell on the other side of the face, from the position; its block ----
       if (state == BW_CROSS && doCross) {
-        const bool yLtX = tny < tnx;
+        const bool yLtX = !NOY && tny < tnx;
         const float m2 = yLtX ? tny : tnx;
         const bool isZ = tnz < m2;  // (the axis whose face was reached: the same comparison the move made)
         const double xw = px + (double)tcur * (double)dx, yw = py + (double)tcur * (double)dy, zw = pz + (double)tcur * (double)dz;
@@ -484,13 +498,13 @@ trace_block_kernel(const DevParams p) {
           if (jy >= p.ny) { jy = 0; py -= p.Ly; if (DEBUG) dbgY -= p.ny; }            // periodic y :1790-1796: continue in the next image
           else if (jy < 0) { jy = p.ny - 1; py += p.Ly; if (DEBUG) dbgY += p.ny; }
           jx = locX(xw, (spans & 1u) != 0);
-          jz = locate_z(s_edge + offZ, p.nz, p.zRegular != 0, p.z0, invDz, zw);
+          jz = locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw);
         } else {
           jx = dx >= 0.0f ? fx : fx - 1;
           if (jx >= p.nx) { jx = 0; px -= p.Lx; if (DEBUG) dbgX -= p.nx; }            // periodic x :1782-1788
           else if (jx < 0) { jx = p.nx - 1; px += p.Lx; if (DEBUG) dbgX += p.nx; }
           jy = locY(yw, (spans & 2u) != 0);
-          jz = locate_z(s_edge + offZ, p.nz, p.zRegular != 0, p.z0, invDz, zw);
+          jz = locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw);
         }
         enterBlock(jx, jy, jz);
         state = BW_MOVE;
@@ -500,7 +514,7 @@ trace_block_kernel(const DevParams p) {
 
       // ---- move: to the collision point inside this block, or to the block face ahead (:1718-1744) ----
       if (state == BW_MOVE) {
-        const bool yLtX = tny < tnx;
+        const bool yLtX = !NOY && tny < tnx;
         const float m2 = yLtX ? tny : tnx;
         const bool isZ = tnz < m2;
         const float tmin = isZ ? tnz : m2;

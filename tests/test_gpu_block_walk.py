@@ -104,6 +104,74 @@ def test_block_walk_forced_on_a_medium_without_blocks(M):
     integ.finalize()
 
 
+def layered_two_component_medium():
+    """6 x 4 x 12 cells, regular spacing: three homogeneous cloud slabs of four layers each (three blocks that span both
+    periodic axes) plus a second, horizontally uniform component with its own albedo and phase function -- the
+    component pick and the per-component tables inside the block-walk kernel."""
+    nx, ny, nz = 6, 4, 12
+    ext = np.zeros((nx, ny, nz))
+    ext[:, :, 0:4], ext[:, :, 4:8], ext[:, :, 8:12] = 3.0, 20.0, 7.0
+    gas = np.full(nz, 1.5)
+    return dict(name="layered2", xe=0.05 * np.arange(nx + 1), ye=0.05 * np.arange(ny + 1), ze=0.025 * np.arange(nz + 1), albedo=0.4,
+                components=[dict(ext=ext, ssa=np.full_like(ext, 0.98), pfIndex=np.ones(ext.shape, np.int32),
+                                 legendre=[cases.hg_legendre(0.85, 48)]),
+                            dict(ext=gas, ssa=np.full(nz, 0.6), pfIndex=np.ones(nz, np.int32),
+                                 legendre=[np.array([0.0, 0.1], np.float32)])])
+
+
+def test_block_walk_with_two_components(M):
+    from oracle import oracle as O
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = layered_two_component_medium()
+    n = 150000
+    photons = M.new_PhotonStream(0.8, 70.0, numberOfPhotons=10 ** 9)
+    dom, integ = _integ(M, case, 1)
+    got = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+    cnt = integ.counters()
+    assert cnt["walkIterations"] < 0.2 * cnt["crossings"]  # (block crossings, not cell faces: the block walk did run)
+    P = cases.oracle_problem(case)
+    ref = O.compute_rt(P, O.solar_source(0.8, 70.0), O.philox_rng(SEED, 0), n, want_fates=True)
+    assert _same(got, ref["fates"]).mean() > 0.998, _same(got, ref["fates"]).mean()
+    for k in ("legs", "crossings", "collisions", "absorbEvents", "topExits", "surfaceHits"):
+        assert abs(cnt[k] - ref["counters"][k]) <= 2e-3 * max(ref["counters"][k], 1) + 5, (k, cnt[k], ref["counters"][k])
+    integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+    res = integ.reportResults()
+    norm = O.normalize(P, n, ref)
+    mu, md, ma, prof = O.report_means(P, norm)
+    for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
+        assert abs(g - r) < 2e-3 * max(r, 0.05), (g, r)
+    assert np.allclose(res["absorbedProfile"], prof, rtol=0.01, atol=1e-5 * np.max(prof) + 1e-9)
+    integ.finalize()
+
+
+def test_xz_specialisation_equals_the_3d_kernel(M):
+    """A domain one cell wide in y runs the instantiation with the y position compiled out (SIMPLE = 2).  The same
+    medium cut into TWO rows in y runs the 3-D instantiation on the very same photons (same Philox streams, same x-z
+    histories): column fluxes summed over the rows, the absorption profile and the domain means must agree to float
+    rounding of the normalisation."""
+    from mcbrat3d_amd import driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    one = cases.step_cloud(0.99)
+    two = cases.step_cloud(0.99)
+    two["ye"] = np.array([0.0, 0.25, 0.5])
+    c = two["components"][0]
+    for k in ("ext", "ssa", "pfIndex"):
+        c[k] = np.repeat(c[k], 2, axis=1)
+    out = []
+    for case in (one, two):
+        dom, integ = _integ(M, case, 1)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), M.new_PhotonStream(0.6, 35.0, numberOfPhotons=10 ** 9), 100000, 5)
+        out.append(driver.statistics(driver.unpack_moments(integ.moments(), dom.numX, dom.numY, dom.numZ)))
+        integ.finalize()
+    a, b = out
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert abs(a[k] - b[k]) < 2e-7, (k, a[k], b[k])
+    for k in ("fluxUp", "fluxDown", "fluxAbsorbed"):
+        assert np.allclose(a[k][:, 0], b[k].mean(axis=1), rtol=2e-6, atol=1e-7), k
+    assert np.allclose(a["absorbedProfile"], b["absorbedProfile"], rtol=2e-6, atol=1e-9)
+
+
 def test_block_walk_thermal_source_small_domain(M):
     """LW emission on an LDS-resident homogeneous domain (one block that spans both periodic axes): launches from the
     voxel CDF and the surface, emission tallied as negative absorption, against the oracle on the same photons."""

@@ -57,12 +57,12 @@ def test_gpu_agrees_with_the_mt_oracle(M, name, make, kw, mu0, phi0, gpu_batches
 def test_full_grid_agrees_with_the_mt_oracle(M, name, make):
     """BASELINE.json configs[2] / [4] on their full 128x128x64 grids: 10^8 GPU photons (100 batches of 10^6) against
     6.4x10^6 photons of the oracle in MT mode (64 batches of 10^5 on the host cores, a few seconds).  The column bins
-    (49 152) are dominated by the CPU sample's noise; the domain means and the per-level absorption profile are the
-    sharp part of this test."""
+    (49 152) hold ~130 CPU photons each, too few for a Gaussian maximum test (their mean and spread are still checked);
+    the domain means and the per-level absorption profile are the sharp part of this test."""
     g = _gpu(M, getattr(cases, make)(), 0.5, 30.0, 10 ** 6, 100)
     c = stats.oracle_run(make, {}, "mt", 64, 100000, 0.5, 30.0, seed=10, procs=16)
     C = {q: stats.mean_err(c[q]) for q in stats.QUANTITIES}
-    print(stats.assert_parity(g, C, name))
+    print(stats.assert_parity(g, C, name, bin_max=False))
 
 
 def test_block_walk_and_face_by_face_walk_agree_with_the_mt_oracle(M):
