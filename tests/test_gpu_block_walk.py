@@ -151,15 +151,20 @@ def test_xz_specialisation_equals_the_3d_kernel(M):
     rounding of the normalisation."""
     from mcbrat3d_amd import driver
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
-    one = cases.step_cloud(0.99)
-    two = cases.step_cloud(0.99)
-    two["ye"] = np.array([0.0, 0.25, 0.5])
-    c = two["components"][0]
-    for k in ("ext", "ssa", "pfIndex"):
-        c[k] = np.repeat(c[k], 2, axis=1)
+    def slabs(ny):  # a 16 x ny x 16 step cloud (small enough that both versions keep grid, tallies and table in LDS)
+        ext = np.zeros((16, ny, 16))
+        ext[:8], ext[8:] = 6.0, 40.0
+        return dict(name="slabs%d" % ny, xe=0.03125 * np.arange(17), ye=np.linspace(0.0, 0.5, ny + 1), ze=0.015625 * np.arange(17),
+                    albedo=0.0, components=[dict(ext=ext, ssa=np.full_like(ext, 0.99), pfIndex=np.ones(ext.shape, np.int32),
+                                                 legendre=[cases.hg_legendre(0.85, 64)])])
     out = []
-    for case in (one, two):
+    for case in (slabs(1), slabs(2)):
         dom, integ = _integ(M, case, 1)
+        integ.enableCounters(True)  # (instrumented once, to see that the block walk is what runs for both)
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), M.new_PhotonStream(0.6, 35.0, numberOfPhotons=10 ** 9), 20000, 1)
+        cnt = integ.counters()
+        assert cnt["walkIterations"] < 0.2 * cnt["crossings"], cnt
+        integ.enableCounters(False)
         integ.resetMoments()
         integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), M.new_PhotonStream(0.6, 35.0, numberOfPhotons=10 ** 9), 100000, 5)
         out.append(driver.statistics(driver.unpack_moments(integ.moments(), dom.numX, dom.numY, dom.numZ)))
