@@ -164,10 +164,12 @@ def pmc_record(workload):
         return json.load(f).get(workload, {})
 
 
-def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False):
+def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False, block_walk=True):
     bpp = algorithmic_bytes_per_photon(cnt, per_step, nc)
     achieved = bpp * per_step / (launch_ms * 1e-3) / 1e9
     rec = pmc_record(workload)
+    if workload == "i3rcStepCloud" and not block_walk:
+        rec = {}  # (the counters on file are the block-walk kernel's: they do not describe the face-by-face run)
     scale = per_step / rec.get("photons_per_launch", per_step)
     traffic = rec["hbm_bytes_per_launch"] * scale if rec.get("hbm_bytes_per_launch") is not None else None
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -486,7 +488,7 @@ def main():
                        "photons_in_reduced_moments_last_step": reduced_photons,
                        "pipelined_steps": bool(a.pipeline), "event_threshold": integ.eventThreshold(),
                        "walk": integ.walkMode()},
-            "roofline": roofline_block(a.workload, cnt, per_step, nc, launch_ms, a.pipeline),
+            "roofline": roofline_block(a.workload, cnt, per_step, nc, launch_ms, a.pipeline, integ.walkMode()["blockWalk"]),
         }
         if not a.no_cpu_baseline:
             cb, batches, cols, ccnt, ctot, prof = cpu_baseline(a.workload, a.cpu_photons_per_core, a.cpu_cores)

@@ -16,7 +16,12 @@ from collections import defaultdict
 
 root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
+files = []
+for d in sorted(glob.glob(os.path.join(root, "pass*"))):  # (a pass directory may hold the files of earlier runs: the newest one counts)
+    cand = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if cand:
+        files.append(max(cand, key=os.path.getmtime))
+for f in files:
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
