@@ -104,6 +104,12 @@ class SpectralRun:
                 it.bindMoments(ptr)
             self._bound = True
 
+    def bindMoments(self, device_ptr):
+        """All wavelengths accumulate into a caller-owned device buffer (the tensor a multi-GPU run all-reduces)."""
+        self.first.bindMoments(device_ptr)
+        self._bound = False
+        self._bind()
+
     def prepare_thermal(self, surfaceTemp):
         """Set-up pass (driver :304-433): emission weights and emitted power of every wavelength, the power CDF; uploads."""
         widths = spectral_widths([d.lambda_um for d in self.domains])

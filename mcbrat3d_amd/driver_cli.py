@@ -182,7 +182,7 @@ def run_spectral(cfg, doms, rank, world, local, dist):
     if dist is not None:
         import torch
         moments = torch.zeros(8 + 2 * run.first.momentsLength(), dtype=torch.float64, device="cuda:%d" % local)
-        run.first.bindMoments(moments.data_ptr())
+        run.bindMoments(moments.data_ptr())
     run.resetMoments()
     if nb > 0:
         # this rank's photons: ids and wavelength draws [lo * ppb, (lo + nb) * ppb)

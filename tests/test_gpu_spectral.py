@@ -97,6 +97,16 @@ def test_resident_thermal_spectrum_matches_the_oracle_loop(M):
     assert np.all(np.abs(got - mean) < 2e-3 * total), (got, mean)
     assert st["batches"] == nbatches
     assert st["meanFluxAbsorbed"] < 0 < st["meanFluxUp"]
+    # a caller-owned moment buffer (what a multi-GPU run all-reduces): every wavelength's context must follow it
+    import torch
+    buf = torch.zeros(8 + 2 * run.first.momentsLength(), dtype=torch.float64, device="cuda:0")
+    run.bindMoments(buf.data_ptr())
+    run.resetMoments()
+    run.run(ppb, nb, new_RandomNumberSequence(SEED), seed=3)
+    torch.cuda.synchronize()
+    st3 = driver.statistics(driver.unpack_moments(buf.cpu().numpy(), 20, 20, 20), solarFlux=flux)
+    assert st3["totalPhotons"] == ppb * nb and st3["meanFluxUp"] == st["meanFluxUp"]
+    assert np.array_equal(st3["absorbedVolume"], st["absorbedVolume"])
     run.finalize()
 
 
