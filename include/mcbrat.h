@@ -250,6 +250,14 @@ int mcbrat_forward_table_tabulated(int32_t nStored, const float *scatteringAngle
 /* computeHybridPhaseFunctions (opticalProperties.f95:1937-2009) on values[nEntries][nAngles]. */
 int mcbrat_hybrid_phase_functions(int32_t nAngles, int32_t nEntries, const float *values,
                                   float gaussianWidthDeg, float *hybridValues);
+/* The decomposition the block walk uses (mcbrat_set_walk_options, blockWalk): axis-aligned boxes of cells with one
+ * extinction value, found greedily (x, then y, then z).  extinction[nx*ny*nz] (x fastest, as the kernels hold it:
+ * float); blockOf[nx*ny*nz]: the block of each cell; blockRec[4*nBlocks] (room for 4*nx*ny*nz): per block
+ * {x0 | x1 << 16, y0 | y1 << 16, z0 | z1 << 16, flags}, cell range [lo, hi) per axis, flag bit 0 / 1 = the block
+ * spans the whole periodic x / y axis.  Host arithmetic only.  Returns 1 for more than 65535 blocks / cells per axis. */
+int mcbrat_block_decomposition(int32_t nx, int32_t ny, int32_t nz, const float *extinction, uint16_t *blockOf,
+                               uint32_t *blockRec, int32_t *nBlocks);
+
 /* emission_weighting (src/emissionAndBroadBandWeights.f95:424-550): builds
  * voxelWeights (running CDF, x fastest), fracAtmsPower and the emitted flux. */
 int mcbrat_emission_weighting(int32_t nx, int32_t ny, int32_t nz, int32_t nComponents,

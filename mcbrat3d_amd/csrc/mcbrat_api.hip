@@ -348,10 +348,8 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
   return 0;
 }
 
-// Block walk (mcbrat_blockwalk.hip): cuts the grid into axis-aligned blocks of cells that carry one extinction value.
-// Greedy: the first cell without a block (x fastest) grows along x, then the row grows along y, then the slab along z,
-// as long as every new cell has the same extinction and no block yet.  Any partition into such blocks is valid; this
-// one finds the two slabs of the I3RC step cloud, the one slab of a plane-parallel medium and the clear air around clouds.
+// Block walk (mcbrat_blockwalk.hip): the grid cut into axis-aligned blocks of cells that carry one extinction value
+// (mcbrat_block_decomposition, mcbrat_host.cpp), uploaded for the kernel.
 int build_blocks(mcbrat_ctx *c, const std::vector<float> &e) {
   const int nx = c->nx, ny = c->ny, nz = c->nz;
   const size_t nvox = (size_t)nx * ny * nz;
@@ -360,42 +358,12 @@ int build_blocks(mcbrat_ctx *c, const std::vector<float> &e) {
   if (c->dBlockOf) { (void)hipFree(c->dBlockOf); c->dBlockOf = nullptr; }
   // only grids that can live in LDS are walked this way (plan_launch decides); bounds are packed in 16 bits
   if (nvox > 65536 || nx > 65535 || ny > 65535 || nz > 65535) return 0;
-  std::vector<int> of(nvox, -1);
-  std::vector<uint32_t> rec;
-  auto at = [&](int i, int j, int k) { return (size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k); };
-  for (int k = 0; k < nz; ++k)
-    for (int j = 0; j < ny; ++j)
-      for (int i = 0; i < nx; ++i) {
-        if (of[at(i, j, k)] >= 0) continue;
-        const float v = e[at(i, j, k)];
-        int x1 = i + 1, y1 = j + 1, z1 = k + 1;
-        while (x1 < nx && of[at(x1, j, k)] < 0 && e[at(x1, j, k)] == v) ++x1;
-        for (; y1 < ny; ++y1) {
-          bool ok = true;
-          for (int ii = i; ii < x1 && ok; ++ii) ok = of[at(ii, y1, k)] < 0 && e[at(ii, y1, k)] == v;
-          if (!ok) break;
-        }
-        for (; z1 < nz; ++z1) {
-          bool ok = true;
-          for (int jj = j; jj < y1 && ok; ++jj)
-            for (int ii = i; ii < x1 && ok; ++ii) ok = of[at(ii, jj, z1)] < 0 && e[at(ii, jj, z1)] == v;
-          if (!ok) break;
-        }
-        const int id = (int)(rec.size() / 4);
-        for (int kk = k; kk < z1; ++kk)
-          for (int jj = j; jj < y1; ++jj)
-            for (int ii = i; ii < x1; ++ii) of[at(ii, jj, kk)] = id;
-        rec.push_back((uint32_t)i | ((uint32_t)x1 << 16));
-        rec.push_back((uint32_t)j | ((uint32_t)y1 << 16));
-        rec.push_back((uint32_t)k | ((uint32_t)z1 << 16));
-        rec.push_back((i == 0 && x1 == nx ? 1u : 0u) | (j == 0 && y1 == ny ? 2u : 0u));
-      }
-  const size_t nb = rec.size() / 4;
-  if (nb > 65535) return 0;
-  std::vector<uint16_t> of16(nvox);
-  for (size_t v = 0; v < nvox; ++v) of16[v] = (uint16_t)of[v];
-  if (upload(c, &c->dBlockRec, rec.data(), rec.size()) || upload(c, &c->dBlockOf, of16.data(), of16.size())) return 1;
-  c->nBlocks = (int)nb;
+  std::vector<uint16_t> of(nvox);
+  std::vector<uint32_t> rec(4 * nvox);
+  int32_t nb = 0;
+  if (mcbrat_block_decomposition(nx, ny, nz, e.data(), of.data(), rec.data(), &nb) != 0) return 0;  // (more than 65535 blocks: face-by-face walk)
+  if (upload(c, &c->dBlockRec, rec.data(), (size_t)4 * nb) || upload(c, &c->dBlockOf, of.data(), of.size())) return 1;
+  c->nBlocks = nb;
   return 0;
 }
 

@@ -334,3 +334,55 @@ extern "C" int mcbrat_emission_weighting(int32_t nx, int32_t ny, int32_t nz, int
   if (totalFlux) *totalFlux = (power / (wx * wy * km2)) * dLambda;
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Block decomposition for the block walk (mcbrat_blockwalk.hip): axis-aligned boxes of cells that carry one
+// extinction value.  Greedy: the first cell without a block (x fastest) grows along x, then the row grows along y,
+// then the slab along z, as long as every new cell has the same extinction and no block yet.  Any partition into
+// such boxes is valid for the walk; this one finds the two slabs of the I3RC step cloud, the one slab of a
+// plane-parallel medium and the clear air around clouds.  Host arithmetic only (no device needed).
+//   blockOf [nx*ny*nz]   block of each cell (x fastest)
+//   blockRec[4*nBlocks]  per block {x0 | x1 << 16, y0 | y1 << 16, z0 | z1 << 16, flags}: cell range [lo, hi) per axis;
+//                        flag bit 0 / 1: the block spans the whole (periodic) x / y axis
+// Returns 0, or 1 when the grid has more than 65535 blocks or an axis longer than 65535 cells.
+// ------------------------------------------------------------------------------------------------
+extern "C" int mcbrat_block_decomposition(int32_t nx, int32_t ny, int32_t nz, const float *ext, uint16_t *blockOf,
+                                          uint32_t *blockRec, int32_t *nBlocks) {
+  if (nx < 1 || ny < 1 || nz < 1 || nx > 65535 || ny > 65535 || nz > 65535 || !ext || !blockOf || !blockRec || !nBlocks) return 1;
+  const size_t nvox = (size_t)nx * ny * nz;
+  std::vector<int> of(nvox, -1);
+  auto at = [&](int i, int j, int k) { return (size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k); };
+  size_t nb = 0;
+  for (int k = 0; k < nz; ++k)
+    for (int j = 0; j < ny; ++j)
+      for (int i = 0; i < nx; ++i) {
+        if (of[at(i, j, k)] >= 0) continue;
+        if (nb >= 65535) return 1;
+        const float v = ext[at(i, j, k)];
+        int x1 = i + 1, y1 = j + 1, z1 = k + 1;
+        while (x1 < nx && of[at(x1, j, k)] < 0 && ext[at(x1, j, k)] == v) ++x1;
+        for (; y1 < ny; ++y1) {
+          bool ok = true;
+          for (int ii = i; ii < x1 && ok; ++ii) ok = of[at(ii, y1, k)] < 0 && ext[at(ii, y1, k)] == v;
+          if (!ok) break;
+        }
+        for (; z1 < nz; ++z1) {
+          bool ok = true;
+          for (int jj = j; jj < y1 && ok; ++jj)
+            for (int ii = i; ii < x1 && ok; ++ii) ok = of[at(ii, jj, z1)] < 0 && ext[at(ii, jj, z1)] == v;
+          if (!ok) break;
+        }
+        for (int kk = k; kk < z1; ++kk)
+          for (int jj = j; jj < y1; ++jj)
+            for (int ii = i; ii < x1; ++ii) of[at(ii, jj, kk)] = (int)nb;
+        blockRec[4 * nb + 0] = (uint32_t)i | ((uint32_t)x1 << 16);
+        blockRec[4 * nb + 1] = (uint32_t)j | ((uint32_t)y1 << 16);
+        blockRec[4 * nb + 2] = (uint32_t)k | ((uint32_t)z1 << 16);
+        blockRec[4 * nb + 3] = (i == 0 && x1 == nx ? 1u : 0u) | (j == 0 && y1 == ny ? 2u : 0u);
+        ++nb;
+      }
+  for (size_t v = 0; v < nvox; ++v) blockOf[v] = (uint16_t)of[v];
+  *nBlocks = (int32_t)nb;
+  return 0;
+}
