@@ -453,6 +453,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # Untimed extra (N = 1, synchronous default run only): the same K steps with consecutive calls allowed to overlap on
+    # the GPU (mcbrat_set_async).  A 1e7-photon launch ends with a tail in which most lanes wait for the last histories
+    # (26 photons per lane); overlapping calls fills it.  Reported beside `value`, never as `value`: kernel durations
+    # under overlap include time spent waiting for compute units, so they stop describing the kernel.
+    pipelined_rate = None
+    if world == 1 and not a.pipeline:
+        integ.setAsync(True)
+        t1 = time.perf_counter()
+        for i in range(a.steps):
+            rng.nextPhotonId = (a.warmup + a.steps + i) * per_step
+            photons.currentPhoton = 1
+            integ.resetMoments()
+            integ.computeRadiativeTransfer(dom, rng, photons, ppb, nb)
+        integ.synchronize()
+        pipelined_rate = per_step * a.steps / (time.perf_counter() - t1)
+        integ.setAsync(False)
+        step(a.warmup + a.steps - 1)  # (the moment arrays hold the last timed step again)
+        sync()
+
     out = None
     if rank == 0:
         # the moment arrays now hold the last step: world * per_step photons, reduced over ranks
@@ -486,7 +505,8 @@ def main():
                        "world_size": dist.get_world_size() if dist is not None else 1,
                        **({"rehearsal": "gloo, all ranks on cuda:0 -- not a measurement"} if rehearse else {}),
                        "photons_in_reduced_moments_last_step": reduced_photons,
-                       "pipelined_steps": bool(a.pipeline), "event_threshold": integ.eventThreshold(),
+                       "pipelined_steps": bool(a.pipeline), "pipelined_photons_per_s_untimed_extra": pipelined_rate,
+                       "event_threshold": integ.eventThreshold(),
                        "walk": integ.walkMode()},
             "roofline": roofline_block(a.workload, cnt, per_step, nc, launch_ms, a.pipeline, integ.walkMode()["blockWalk"]),
         }
