@@ -338,6 +338,9 @@ def main():
                     help="let consecutive steps overlap on the GPU (asynchronous mode of the library: hides each "
                          "launch's drain; per-kernel durations then include time spent waiting for compute units, so "
                          "the default run, whose kernel durations rocprofv3 must reproduce, does not use it)")
+    ap.add_argument("--pipelined-extra", action="store_true",
+                    help="after the timed steps, run them once more with overlapping calls and report that rate as an "
+                         "untimed extra in config (not in the default run: its kernel launches would enter a profiler's averages)")
     ap.add_argument("--dry-run", action="store_true", help="rehearse launcher + collective on CPU (gloo), no tracing")
     a = ap.parse_args()
 
@@ -453,12 +456,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # Untimed extra (N = 1, synchronous default run only): the same K steps with consecutive calls allowed to overlap on
+    # Untimed extra (--pipelined-extra, N = 1): the same K steps with consecutive calls allowed to overlap on
     # the GPU (mcbrat_set_async).  A 1e7-photon launch ends with a tail in which most lanes wait for the last histories
     # (26 photons per lane); overlapping calls fills it.  Reported beside `value`, never as `value`: kernel durations
     # under overlap include time spent waiting for compute units, so they stop describing the kernel.
     pipelined_rate = None
-    if world == 1 and not a.pipeline:
+    if world == 1 and not a.pipeline and a.pipelined_extra:
         integ.setAsync(True)
         t1 = time.perf_counter()
         for i in range(a.steps):

@@ -1,0 +1,14 @@
+#!/bin/bash
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/r02c24
+mkdir -p $OUT
+cd $ROOT
+for c in landsat radar; do
+python scripts/ab_compare.py $c 32 >> $OUT/ab.log 2>&1
+for w in 6 7; do
+MCBRAT_LIB=$ROOT/ab/libmcbrat_comb$w.so python scripts/ab_compare.py $c 32 >> $OUT/ab.log 2>&1
+done
+done
+grep lib= $OUT/ab.log
+echo finished
