@@ -218,7 +218,8 @@ int mcbrat_set_surface_description(mcbrat_ctx *ctx, int32_t numX, int32_t numY, 
  * small domains): the grid is cut into axis-aligned blocks of cells that carry one extinction value, and a leg goes
  * from block face to block face instead of from cell face to cell face; the cell of a collision or an exit is found
  * from the position.  Same argument as for layerSkip: inside a block the reference's stops at cell faces only add
- * `segment x the same extinction` again.  0 restores the face-by-face walk. */
+ * `segment x the same extinction` again.  0 restores the face-by-face walk; 2 uses the block walk even where blocks
+ * hold fewer than four cells on average (a medium that differs from cell to cell: slower, meant for tests). */
 int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t blockWalk);
 /* The walk options in force: bit 0 layerSkip, bit 1 blockWalk. */
 int mcbrat_get_walk_mode(const mcbrat_ctx *ctx);
