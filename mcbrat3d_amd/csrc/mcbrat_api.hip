@@ -59,6 +59,11 @@ struct mcbrat_ctx {
   float *dLayerExt = nullptr;  // [nz] extinction of a horizontally uniform layer, -1 otherwise
   int *dLayerRun = nullptr;    // [nz] runs of such layers (DevParams::layerRun)
   double *dLayerRunT = nullptr;  // [nz+1]
+  // clear-air flight (DevParams::fly...)
+  float *dExtWalk = nullptr, *dBgVal = nullptr;
+  uint16_t *dFlyRange = nullptr;
+  int flyNbx = 0, flyNby = 0;
+  bool flyBuilt = false;
   // block walk (mcbrat_blockwalk.hip)
   uint32_t *dBlockRec = nullptr;
   uint16_t *dBlockOf = nullptr;
@@ -123,7 +128,8 @@ struct mcbrat_ctx {
   int rayShort = 0, rayPassIters = 0, rayPassAt = 0;  // 0: chosen in launch_trace_b (MCBRAT_RAY_SHORT, MCBRAT_RAY_PASS_ITERS, MCBRAT_RAY_PASS_AT)
   int rayDefer = 1;            // radiance: long rays are put aside and finished in dense passes (MCBRAT_RAY_DEFER=0: inside their event phase)
   int blockWalk = 1;           // LDS-resident grids: blocks of cells with one extinction value are crossed in one step (MCBRAT_BLOCK_WALK=0 / mcbrat_set_walk_options)
-  int layerSkip = 1;           // layers of one extinction value: cross z faces only (MCBRAT_LAYER_SKIP=0 / mcbrat_set_walk_options)
+  int layerSkip = 1;           // layers of one extinction value: cross z faces only; clear-air flight outside the brick columns' cloud
+                               // ranges (MCBRAT_LAYER_SKIP / mcbrat_set_walk_options: 0 off, 1 both, 2 the layers only)
   bool countersOn = false;
   float lastTraceMs = 0.f;
   mcbrat_counters lastCounters{};
@@ -278,12 +284,60 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
     }
   }
   if (upload(c, &c->dLayerExt, layerExt.data(), layerExt.size())) return 1;
+  std::vector<char> flyable(nz, 0);  // layers in which some brick column lies outside its range (clear-air flight)
+  {
+    // clear-air flight: per brick column (4 x 4 columns) the layers [lo, hi) that hold a cell whose extinction differs
+    // from its layer's background; the walk's copy of the extinction carries the sign bit in every cell outside the
+    // range of its brick column (such a cell holds its layer's background value by construction)
+    c->flyBuilt = false;
+    c->flyNbx = c->flyNby = 0;
+    for (int k = 0; k < nz; ++k) flyable[k] = layerExt[k] >= 0.f ? 1 : 0;
+    if (nx % 4 == 0 && ny % 4 == 0 && nz >= 2 && nz <= 255) {
+      const int fbx = nx / 4, fby = ny / 4;
+      std::vector<uint16_t> range((size_t)fbx * fby);
+      std::vector<float> walk(e);
+      std::fill(flyable.begin(), flyable.end(), 0);
+      for (int by = 0; by < fby; ++by)
+        for (int bx = 0; bx < fbx; ++bx) {
+          int lo = nz, hi = 0;
+          for (int k = 0; k < nz; ++k) {
+            bool differs = false;
+            for (int j = by * 4; j < by * 4 + 4 && !differs; ++j)
+              for (int i = bx * 4; i < bx * 4 + 4 && !differs; ++i)
+                differs = e[(size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k)] != bgExt[k];
+            if (differs) { lo = std::min(lo, k); hi = k + 1; }
+          }
+          range[(size_t)bx + (size_t)fbx * by] = (uint16_t)(lo | (hi << 8));
+          for (int k = 0; k < nz; ++k) {
+            if (k >= lo && k < hi) continue;
+            flyable[k] = 1;
+            for (int j = by * 4; j < by * 4 + 4; ++j)
+              for (int i = bx * 4; i < bx * 4 + 4; ++i) {
+                float &w = walk[(size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k)];
+                uint32_t u;
+                std::memcpy(&u, &w, 4);
+                u |= 0x80000000u;
+                std::memcpy(&w, &u, 4);
+              }
+          }
+        }
+      if (upload(c, &c->dFlyRange, range.data(), range.size()) || upload(c, &c->dExtWalk, walk.data(), walk.size()) ||
+          upload(c, &c->dBgVal, bgExt.data(), bgExt.size()))
+        return 1;
+      c->flyNbx = fbx; c->flyNby = fby;
+      c->flyBuilt = true;
+    }
+  }
   {
     // runs of consecutive one-extinction layers (layer-skipping walk): for layer k the face where its run ends
     // upwards / downwards, and the vertical optical depth of such layers below every face
     std::vector<int> run(nz, 0);
     std::vector<double> runT(nz + 1, 0.0);
-    for (int k = 0; k < nz; ++k) runT[k + 1] = runT[k] + (layerExt[k] >= 0.f ? (double)layerExt[k] * (c->ze[k + 1] - c->ze[k]) : 0.0);
+    // (of the background extinction of every layer a flight can pass through -- one in which some brick column lies
+    // outside its range; the one-extinction layers are among them, and inside a run of those the differences are the
+    // run's own.  A layer no flight can cross adds nothing: differences across it are only used as the bound on what
+    // the background can take from a lane before its flight ends.)
+    for (int k = 0; k < nz; ++k) runT[k + 1] = runT[k] + (flyable[k] ? (double)bgExt[k] * (c->ze[k + 1] - c->ze[k]) : 0.0);
     for (int k = 0; k < nz; ++k) {
       int up = k + 1, down = k;
       while (up < nz && layerExt[up] >= 0.f) ++up;
@@ -399,6 +453,8 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.dXf = (float)((p.xMax - p.x0) / c->nx); p.dYf = (float)((p.yMax - p.y0) / c->ny); p.dZf = (float)((p.zMax - p.z0) / c->nz);
   p.layerSkip = c->layerSkip ? 1 : 0;
   p.layerRun = c->dLayerRun; p.layerRunT = c->dLayerRunT;
+  p.fly = 0; p.flyNbx = p.flyNby = 0;  // (switched on by launch_trace where the plan allows it)
+  p.flyRange = c->dFlyRange; p.bgVal = c->dBgVal;
   p.invLx = 1.0 / p.Lx; p.invLy = 1.0 / p.Ly;
   p.invCellX = (double)c->nx / p.Lx; p.invCellY = (double)c->ny / p.Ly;
   {
@@ -410,10 +466,12 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.edges = c->dEdges;
   if (use_bricks(c)) {
     p.ext = c->dExtB; p.cum = c->dCumB; p.ssa = c->dSsaB; p.pfi = c->dPfiB;
+    p.extWalk = p.ext;
     p.brickTable = c->dBrickTable; p.nbx = c->nbx; p.nby = c->nby; p.nbz = c->nbz; p.nStored = c->nStored;
     p.bgExt = c->dBgExt; p.bgCum = c->dBgCum; p.bgSsa = c->dBgSsa; p.bgPfi = c->dBgPfi;
   } else {
     p.ext = c->dExt; p.cum = c->dCum; p.ssa = c->dSsa; p.pfi = c->dPfi;
+    p.extWalk = p.ext;
     p.bgExt = c->dLayerExt;  // dense layout: the per-layer slot holds the uniform-layer shortcut
     p.rec = reinterpret_cast<const uint4 *>(c->dRec);
   }
@@ -446,11 +504,16 @@ constexpr size_t kLdsBudget = 64 * 1024;      // default dynamic-LDS limit per w
 constexpr size_t kTableLdsLimit = 48 * 1024;   // tables above this stay in L2
 constexpr size_t kPrivSlabLimit = 32 * 1024;   // private tally slab above this -> global atomics
 
-// LDS of the per-layer tables: extinction (float), run (int), cumulative optical depth (double, nz + 1 padded to even)
-size_t per_layer_lds(int nz) { return 2 * sizeof(float) * (size_t)((nz + 3) & ~3) + sizeof(double) * (size_t)((nz + 2) & ~1); }
+// LDS of the per-layer tables: extinction (float), run (int), cumulative optical depth (double, nz + 1 padded to even);
+// clear-air flight: background extinction (float), the brick columns' cloud ranges as heights (2 floats) and layers (u16)
+size_t per_layer_lds(int nz, int flyCols = 0) {
+  return 2 * sizeof(float) * (size_t)((nz + 3) & ~3) + sizeof(double) * (size_t)((nz + 2) & ~1) +
+         (flyCols ? sizeof(float) * (size_t)((nz + 3) & ~3) + 2 * sizeof(float) * (size_t)flyCols + sizeof(uint16_t) * (size_t)((flyCols + 3) & ~3) : 0);
+}
 
 struct LaunchPlan {
   bool tblLds, priv, brick, gridLds;
+  bool fly;  // clear-air flight: dense grid in global memory, flux run, tables built, room in LDS
   int block;
   size_t lds;
 };
@@ -470,12 +533,15 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
   const size_t grid = nvox * 4 + (size_t)c->nc * nvox * (4 + 4) + (((size_t)c->nc * nvox + 1) & ~(size_t)1) * 2;
   L.gridLds = L.priv && c->gridLdsMode != 0 && edges + bg + slab + grid + (L.tblLds ? tbl : 0) <= kLdsBudget;
   L.lds = edges + bg + (L.priv ? slab : 0) + (L.gridLds ? grid : 0) + (L.tblLds ? tbl : 0);
+  const size_t flyLds = per_layer_lds(c->nz, c->flyNbx * c->flyNby) - bg;
+  L.fly = c->layerSkip == 1 && c->flyBuilt && !L.gridLds && !L.brick && c->nDir == 0 && L.lds + flyLds <= kLdsBudget;
+  if (L.fly) L.lds += flyLds;
   L.block = c->blockSize > 0 ? c->blockSize : (L.gridLds ? 768 : ((L.tblLds || L.priv) && L.lds > 16 * 1024 ? 512 : 256));
   return L;
 }
 
 size_t plan_launch_lds(const mcbrat_ctx *c, const LaunchPlan &L) {
-  return sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3) + per_layer_lds(c->nz) +
+  return sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3) + per_layer_lds(c->nz, L.fly ? c->flyNbx * c->flyNby : 0) +
          (L.tblLds ? sizeof(float) * (size_t)c->tblTotalFloats : 0);
 }
 
@@ -514,7 +580,7 @@ int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   if constexpr (BLOCK == 256 && PRIV == 0 && !BRICK && !DBG && !INTEN) {
     // the large flux runs: dense grid in global memory, collision records (nc <= 2), layer-skipping walk, albedo
     // surface -- with the walk's spacing flags decided at compile time too (SPEC, mcbrat_kernels.hip)
-    if (p.rec != nullptr && p.layerSkip && p.surfNumX == 0 && p.xyRegularWalk == p.zRegularWalk) {
+    if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk == p.zRegularWalk) {
       if (p.xyRegularWalk)
         return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 2>(c, p, lds, nBatches)
                                : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 2>(c, p, lds, nBatches);
@@ -623,6 +689,7 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
     L.gridLds = false;
     L.lds = plan_launch_lds(c, L);
   }
+  if (L.fly) { p.fly = 1; p.flyNbx = c->flyNbx; p.flyNby = c->flyNby; p.extWalk = c->dExtWalk; }
   if (block_walk_applies(c, L)) return launch_block(c, p, L, debug, nBatches);
   // small domains (grid, tables and tallies in LDS): LDS holds two workgroups per CU, and two workgroups of 12 waves
   // (6 per SIMD, 80 VGPRs) beat two of 8 (4 per SIMD, no spills) by 10 % on the step cloud (640 and 896 lanes lose)
@@ -722,7 +789,7 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   (void)sync_all(c);
   void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF,
                   c->dEventCounters, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
-                  c->dBlockRec, c->dBlockOf, c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dSurfX, c->dSurfY, c->dSurfRefl};
+                  c->dBlockRec, c->dBlockOf, c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dExtWalk, c->dBgVal, c->dFlyRange, c->dSurfX, c->dSurfY, c->dSurfRefl};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (mcbrat_ctx::Lane &L : c->lane) {
     void *lb[] = {L.dCounter, L.dSlabs, L.dColVals, L.dScalVals};
@@ -1116,7 +1183,7 @@ int mcbrat_set_surface_description(mcbrat_ctx *c, int32_t numX, int32_t numY, co
 
 int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip, int32_t blockWalk) {
   if (!c) return 1;
-  if (layerSkip >= 0) { if ((layerSkip != 0) != (c->layerSkip != 0)) c->tuned = false; c->layerSkip = layerSkip ? 1 : 0; }
+  if (layerSkip >= 0) { if (layerSkip != c->layerSkip) c->tuned = false; c->layerSkip = layerSkip > 2 ? 1 : layerSkip; }
   if (blockWalk >= 0) { if (blockWalk != c->blockWalk) c->tuned = false; c->blockWalk = std::min(blockWalk, 2); }
   return 0;
 }
@@ -1160,7 +1227,7 @@ int mcbrat_frequency_distribution(mcbrat_ctx *c, uint64_t seed, uint64_t firstDr
   return 0;
 }
 
-int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0)) : 0; }
+int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0) | (c->layerSkip == 1 ? 4 : 0)) : 0; }
 
 int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int64_t ppb, int32_t nBatches,
                                       int64_t *numPhotonsProcessed) {

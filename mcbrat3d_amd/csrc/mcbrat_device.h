@@ -14,7 +14,8 @@ constexpr double kTallyInv = 1.0 / 4294967296.0;
 // States of a lane in the tracing loop.
 // ST_ENTER: a lane on the layer-skipping walk has reached a layer whose extinction varies from cell to cell and
 // waits for the event phase to bring its x/y state up to date.
-// ST_JUMP: a lane has entered a run of such layers and waits for the event phase to take the run in one step.
+// ST_JUMP: a lane has entered a run of such layers and waits for the event phase to take the run in one step -- or
+// has entered a cell outside its brick column's cloud range and waits for the event phase to start a clear-air flight.
 enum : int { ST_DEAD = 0, ST_WALK = 1, ST_COLLIDE = 2, ST_SURFACE = 3, ST_TOP = 4, ST_ENTER = 5, ST_JUMP = 6 };
 
 struct DevParams {
@@ -30,7 +31,15 @@ struct DevParams {
   // cell is found again from the position (periodic fold + cell lookup) when the lane leaves such layers
   int layerSkip;
   const int *layerRun;            // [nz] run of one-extinction layers around layer k: face where it ends upwards << 16 | downwards
-  const double *layerRunT;        // [nz+1] vertical optical depth of the one-extinction layers below face f
+  const double *layerRunT;        // [nz+1] vertical optical depth of the layers' background extinction below face f
+  // clear-air flight (dense layout, flux runs; mcbrat_kernels.hip): columns are grouped 4 x 4 into brick columns; outside the
+  // layers [lo, hi) in which a brick column holds a cell that differs from its layer's background extinction, a lane
+  // whose optical depth cannot be used up by the background alone steps from brick column to brick column
+  int fly;
+  int flyNbx, flyNby;             // brick columns along x / y (0: off)
+  const uint16_t *flyRange;       // [flyNby][flyNbx] lo | hi << 8 (lo = nz, hi = 0: the brick column is background throughout)
+  const float *extWalk;           // [nvox] what the photons' walk reads: ext, with the sign bit set in the cells outside their brick column's range (fly off: ext itself)
+  const float *bgVal;             // [nz] background extinction of every layer (its most common value)
   int xyNearUniform;              // x and y edges equally spaced to 1e-6 of a cell: cell guess by division, table decides
   double invLx, invLy;            // 1 / domain length
   double invCellX, invCellY;      // nx / Lx, ny / Ly
