@@ -726,7 +726,7 @@ int autotune(mcbrat_ctx *c, DevParams p, unsigned long long ppb, int nBatches) {
   const int nb = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)nBatches, want / std::max<unsigned long long>(1, ppb)));
   p.total = std::min(want, ppb * (unsigned long long)nb);
   p.fates = nullptr; p.counters = nullptr;
-  const int candidates[] = {8, 16, 24, 32, 48};
+  const int candidates[] = {8, 16, 20, 24, 32, 48};
   float best = 1e30f;
   int bestThr = c->eventThreshold;
   for (int thr : candidates) {
@@ -1227,7 +1227,7 @@ int mcbrat_frequency_distribution(mcbrat_ctx *c, uint64_t seed, uint64_t firstDr
   return 0;
 }
 
-int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0) | (c->layerSkip == 1 ? 4 : 0)) : 0; }
+int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0) | (c->layerSkip == 1 && c->flyBuilt ? 4 : 0)) : 0; }
 
 int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int64_t ppb, int32_t nBatches,
                                       int64_t *numPhotonsProcessed) {

@@ -215,7 +215,7 @@ class Integrator:
 
     def walkMode(self):
         m = int(self._lib.mcbrat_get_walk_mode(self._ctx))
-        return {"layerSkip": bool(m & 1), "blockWalk": bool(m & 2)}
+        return {"layerSkip": bool(m & 1), "blockWalk": bool(m & 2), "clearAirFlight": bool(m & 4)}
 
     def eventThreshold(self):
         return int(self._lib.mcbrat_get_event_threshold(self._ctx))

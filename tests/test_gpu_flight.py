@@ -1,0 +1,174 @@
+"""The clear-air flight (include/mcbrat.h: mcbrat_set_walk_options, layerSkip = 1) through the C ABI on the GPU.
+
+Columns are grouped 4 x 4 into brick columns; outside the layers in which a brick column holds a cell that differs
+from its layer's background extinction, a photon whose optical depth cannot be used up by the background steps from
+brick column to brick column and takes its optical depth from the background's vertical optical depth when the flight
+ends (mcbrat_kernels.hip, FLY).  The reference (accumulateExtinctionAlongPath, src/opticalProperties.f95:1697-1814) and
+the oracle stop at every cell face, which in background cells changes nothing but the float rounding of the
+accumulated optical depth.  So: histories against the kernel's own walk without the flight (layerSkip = 2: one-extinction
+layers only; 0: face by face) and against the oracle on the same Philox streams, the count of faces crossed, and the
+cases the flight has to get right: vacuum background (the mark is a sign bit on 0.0), a background thick enough to
+collide in, periodic wraps at a grazing sun, a reflecting surface under the clouds, equally spaced and stretched
+grids, grids whose column count is not a multiple of four (no flight)."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+SEED = 90210
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mcbrat3d_amd
+    return mcbrat3d_amd
+
+
+def _run(M, case, mu0, phi0, skip, n, rr=True, nsteps=9001, batches=2):
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=nsteps, useRayTracing=True, useRussianRoulette=rr)
+    integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=skip)  # (grid in global memory: where the flight lives)
+    photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+    rng = new_RandomNumberSequence(SEED)
+    fates = integ.traceFates(dom, rng, photons, n)
+    mode = integ.walkMode()  # (after the domain has been handed over: that is when the brick columns are built)
+    counters = integ.counters()
+    integ.resetMoments()
+    integ.computeRadiativeTransfer(dom, rng, photons, n, batches)
+    r = integ.reportResults()
+    integ.finalize()
+    return dict(fates=fates, counters=counters, mode=mode, res=r,
+                means=np.array([r["meanFluxUp"], r["meanFluxDown"], r["meanFluxAbsorbed"]]))
+
+
+def _same(a, b):
+    return (a["fate"] == b["fate"]) & (a["ix"] == b["ix"]) & (a["iy"] == b["iy"]) & (a["iz"] == b["iz"]) & \
+        (a["nScatter"] == b["nScatter"]) & (np.abs(a["weight"] - b["weight"]) <= 1e-6)
+
+
+def blobs(nx=16, ny=12, nz=20, seed=5, background=0.0, albedo=0.0, regular=True, ssa=0.97, two=False):
+    """A few box-shaped clouds of random extinction in a background that is the same in every cell of a layer (0: vacuum)."""
+    rng = np.random.default_rng(seed)
+    if regular:
+        xe, ye, ze = 0.0625 * np.arange(nx + 1), 0.0625 * np.arange(ny + 1), 0.03125 * np.arange(nz + 1)
+    else:
+        xe = np.concatenate([[0.0], np.cumsum(0.04 * rng.uniform(0.7, 1.4, nx))])
+        ye = np.concatenate([[0.0], np.cumsum(0.05 * rng.uniform(0.7, 1.4, ny))])
+        ze = np.concatenate([[0.0], np.cumsum(0.03 * rng.uniform(0.6, 1.5, nz))])
+    bgp = background * np.exp(-np.arange(nz) / 8.0)
+    ext = np.broadcast_to(bgp, (nx, ny, nz)).copy()
+    for _ in range(int(rng.integers(2, 6))):
+        i0, j0, k0 = int(rng.integers(0, nx)), int(rng.integers(0, ny)), int(rng.integers(1, max(2, nz - 4)))
+        di, dj, dk = int(rng.integers(1, 6)), int(rng.integers(1, 6)), int(rng.integers(1, 5))
+        ii, jj = np.arange(i0, i0 + di) % nx, np.arange(j0, j0 + dj) % ny
+        ext[np.ix_(ii, jj, np.arange(k0, min(k0 + dk, nz - 1)))] = rng.uniform(5.0, 40.0)
+    comps = [dict(ext=ext, ssa=np.where(ext > 0, ssa, 0.0), pfIndex=np.ones(ext.shape, np.int32),
+                  legendre=[cases.hg_legendre(0.8, 32)])]
+    if two:
+        comps.append(dict(ext=0.02 * np.exp(-np.arange(nz) / 6.0), ssa=np.ones(nz), pfIndex=np.ones(nz, np.int32),
+                          legendre=[np.array([0.0, 0.1], np.float32)]))
+    return dict(name="blobs%d" % seed, xe=xe, ye=ye, ze=ze, albedo=albedo, components=comps)
+
+
+def test_cloud_field_against_walk_without_flight_and_oracle(M):
+    """Broken cloud field, two components: the histories are those of the walk without the flight and of the oracle, and
+    the faces a flight skips are counted (crossings per photon agree)."""
+    from oracle import oracle as O
+    n = 40000
+    case = cases.landsat_like(n=48, nz=24, n_entries=6)
+    a, b = _run(M, case, 0.5, 30.0, 2, n), _run(M, case, 0.5, 30.0, 1, n)
+    assert b["mode"]["clearAirFlight"] and not a["mode"]["clearAirFlight"]
+    assert _same(b["fates"], a["fates"]).mean() > 0.99
+    P = cases.oracle_problem(case, nsteps=9001)
+    ref = O.compute_rt(P, O.solar_source(0.5, 30.0), O.philox_rng(SEED, 0), n, want_fates=True)
+    assert _same(b["fates"], ref["fates"]).mean() > 0.99
+    for k in ("legs", "crossings", "collisions", "topExits", "surfaceHits"):
+        assert abs(b["counters"][k] - a["counters"][k]) <= 2e-3 * a["counters"][k] + 5, (k, b["counters"][k], a["counters"][k])
+        assert abs(b["counters"][k] - ref["counters"][k]) <= 2e-3 * ref["counters"][k] + 5, (k, b["counters"][k], ref["counters"][k])
+    assert np.all(np.abs(b["means"] - a["means"]) < 1e-3), (b["means"], a["means"])
+
+
+@pytest.mark.parametrize("mu0,phi0,albedo", [(0.5, 30.0, 0.0), (0.05, 77.0, 0.0), (1.0, 0.0, 0.6), (0.3, 200.0, 0.6)])
+def test_vacuum_background(M, mu0, phi0, albedo):
+    """Clouds in vacuum: the mark of a clear cell is the sign bit of 0.0.  Grazing sun: the direct beam wraps around the
+    periodic domain many times in flight; reflecting surface: flights start at the surface too."""
+    n = 30000
+    case = blobs(background=0.0, albedo=albedo, seed=5 + int(10 * mu0))
+    a, b = _run(M, case, mu0, phi0, 0, n), _run(M, case, mu0, phi0, 1, n)
+    assert b["mode"]["clearAirFlight"]
+    # most of this domain is empty: the walk needs far fewer steps with the flight
+    assert b["counters"]["walkLanes"] < 0.6 * a["counters"]["walkLanes"], (b["counters"]["walkLanes"], a["counters"]["walkLanes"])
+    assert _same(b["fates"], a["fates"]).mean() > 0.99
+    for k in ("legs", "crossings", "collisions", "topExits", "surfaceHits"):
+        assert abs(b["counters"][k] - a["counters"][k]) <= 3e-3 * a["counters"][k] + 5, (k, b["counters"][k], a["counters"][k])
+    assert np.all(np.abs(b["means"] - a["means"]) < 1.5e-3), (b["means"], a["means"])
+    assert abs(b["means"][0] + b["means"][2] + (1.0 - albedo) * b["means"][1] - 1.0) < 4.0 / np.sqrt(n)
+
+
+@pytest.mark.parametrize("background", [0.05, 1.5])
+def test_background_that_photons_collide_in(M, background):
+    """A haze between the clouds: some (0.05 km^-1) or most (1.5 km^-1) flights are refused because the optical depth
+    may run out in the background, those photons walk the marked cells face by face and collide in them."""
+    from oracle import oracle as O
+    n = 30000
+    case = blobs(background=background, albedo=0.2, seed=21, two=True)
+    a, b = _run(M, case, 0.6, 120.0, 0, n), _run(M, case, 0.6, 120.0, 1, n)
+    same = _same(b["fates"], a["fates"])
+    assert same.mean() > 0.98, same.mean()
+    assert same[a["fates"]["nScatter"] <= 2].mean() > 0.995
+    P = cases.oracle_problem(case, nsteps=9001)
+    ref = O.compute_rt(P, O.solar_source(0.6, 120.0), O.philox_rng(SEED, 0), n, want_fates=True)
+    assert _same(b["fates"], ref["fates"]).mean() > 0.98
+    for k in ("legs", "crossings", "collisions", "topExits", "surfaceHits"):
+        assert abs(b["counters"][k] - ref["counters"][k]) <= 3e-3 * ref["counters"][k] + 5, (k, b["counters"][k], ref["counters"][k])
+    assert np.all(np.abs(b["means"] - a["means"]) < 2e-3), (b["means"], a["means"])
+
+
+def test_stretched_grid(M):
+    """Unequal spacing on every axis: brick columns of unequal size; the cell at the end of a flight comes from three
+    edge comparisons per axis inside the brick column."""
+    n = 30000
+    case = blobs(nx=12, ny=8, nz=18, regular=False, background=0.01, albedo=0.3, seed=33)
+    a, b = _run(M, case, 0.4, 250.0, 0, n), _run(M, case, 0.4, 250.0, 1, n)
+    assert b["mode"]["clearAirFlight"]
+    same = _same(b["fates"], a["fates"])
+    assert same.mean() > 0.985, same.mean()
+    assert same[a["fates"]["nScatter"] <= 2].mean() > 0.995
+    for k in ("legs", "crossings", "collisions", "topExits", "surfaceHits"):
+        assert abs(b["counters"][k] - a["counters"][k]) <= 3e-3 * a["counters"][k] + 5, (k, b["counters"][k], a["counters"][k])
+    assert np.all(np.abs(b["means"] - a["means"]) < 2e-3), (b["means"], a["means"])
+
+
+def test_column_count_not_a_multiple_of_four(M):
+    """No brick columns, no flight: bitwise the moments of layerSkip = 2."""
+    n = 20000
+    case = blobs(nx=14, ny=9, nz=12, background=0.0, seed=8)
+    a, b = _run(M, case, 0.7, 10.0, 2, n), _run(M, case, 0.7, 10.0, 1, n)
+    assert not b["mode"]["clearAirFlight"]
+    assert np.array_equal(b["fates"], a["fates"])
+    assert np.array_equal(b["means"], a["means"])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_fields_against_face_by_face_walk(M, seed):
+    """Differential test: random box clouds, random background (vacuum, thin, thick), equal or stretched spacing, one or two
+    components, random sun and surface, column counts that are multiples of four."""
+    rng = np.random.default_rng(7000 + seed)
+    nx, ny, nz = 4 * int(rng.integers(1, 5)), 4 * int(rng.integers(1, 4)), int(rng.integers(4, 18))
+    case = blobs(nx=nx, ny=ny, nz=nz, seed=100 + seed, background=float(rng.choice([0.0, 0.0, 0.02, 0.4, 3.0])),
+                 albedo=float(rng.choice([0.0, 0.3, 0.8])), regular=bool(rng.random() < 0.5), two=bool(rng.random() < 0.5),
+                 ssa=float(rng.uniform(0.7, 1.0)))
+    mu0, phi0 = float(rng.choice([1.0, rng.uniform(0.03, 1.0)])), float(rng.uniform(0.0, 360.0))
+    n = 20000
+    rr = bool(rng.integers(0, 2))
+    a, b = _run(M, case, mu0, phi0, 0, n, rr=rr, batches=1), _run(M, case, mu0, phi0, 1, n, rr=rr, batches=1)
+    same = _same(b["fates"], a["fates"])
+    assert same.mean() > 0.97, (case["name"], nx, ny, nz, same.mean())
+    assert same[a["fates"]["nScatter"] <= 2].mean() > 0.995
+    assert np.all(np.abs(b["means"] - a["means"]) < 4e-3), (b["means"], a["means"])
+    alb = case["albedo"]
+    # (Russian roulette in an absorbing haze restores weights to 1: conservation holds in the mean, with that variance)
+    assert abs(b["means"][0] + b["means"][2] + (1.0 - alb) * b["means"][1] - 1.0) < 6.0 / np.sqrt(n)
