@@ -180,7 +180,7 @@ def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False, block
                "legs", "crossings", "collisions", "absorbEvents", "topExits", "surfaceHits", "rouletteKills", "rouletteSurvivals")},
            "lanes_per_walk_iteration": cnt["walkLanes"] / max(1, cnt["walkIterations"]),
            "lanes_per_event_phase": cnt["eventLanes"] / max(1, cnt["eventPhases"]),
-           "binding_resource": "valu_issue" if workload == "i3rcStepCloud" else "l2_requests",
+           "binding_resource": "valu_issue" if (workload == "i3rcStepCloud" or rec.get("wave_time_waiting", 1.0) < 0.4) else "l2_requests",
            "note": "working set is cache / LDS resident: HBM is not what binds (see valu); DESIGN.md section 5"
                    + ("; --pipeline: kernel durations include waiting for compute units held by the previous launch" if pipeline else "")}
     if rec.get("valu_insts_per_launch"):

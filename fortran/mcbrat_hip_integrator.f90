@@ -424,7 +424,7 @@ contains
     ierr = mcbrat_synchronize(this%ctx)
   end subroutine synchronize
   !------------------------------------------------------------------------------------------
-  ! layerSkip / blockWalk: .false. restores the reference's face-by-face walk (include/mcbrat.h)
+  ! layerSkip (one-extinction layers and the clear-air flight) / blockWalk: .false. restores the reference's face-by-face walk (include/mcbrat.h)
   subroutine setWalkOptions(this, layerSkip, blockWalk, ierr)
     type(integrator), intent(inout) :: this
     logical, intent(in) :: layerSkip, blockWalk

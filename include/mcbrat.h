@@ -214,6 +214,13 @@ int mcbrat_set_surface_description(mcbrat_ctx *ctx, int32_t numX, int32_t numY, 
  * accumulateExtinctionAlongPath (src/opticalProperties.f95:1697-1814) stops at every x and y face too, which changes
  * nothing inside such a layer but the float rounding of the accumulated optical depth; 0 restores that face-by-face
  * walk (used by the per-photon identity tests).
+ * With layerSkip = 1 the same idea is applied inside the other layers too (the clear-air flight): columns are grouped
+ * 4 x 4 into brick columns; outside the layers in which a brick column holds a cell that differs from its layer's most
+ * common ("background") extinction, a photon whose remaining optical depth cannot be used up by the background
+ * between its height and the domain boundary steps from brick column to brick column, and takes its optical depth
+ * from the background's vertical optical depth when that flight ends (at a cloud, or at the domain boundary).  Grids
+ * whose column counts are multiples of four, at most 255 layers, fluxes only.  layerSkip = 2: the one-extinction layers
+ * only, no flight.
  * blockWalk (default 1): domains whose optical grid is resident in LDS (I3RC step cloud, plane-parallel and other
  * small domains): the grid is cut into axis-aligned blocks of cells that carry one extinction value, and a leg goes
  * from block face to block face instead of from cell face to cell face; the cell of a collision or an exit is found
@@ -221,7 +228,8 @@ int mcbrat_set_surface_description(mcbrat_ctx *ctx, int32_t numX, int32_t numY, 
  * `segment x the same extinction` again.  0 restores the face-by-face walk; 2 uses the block walk even where blocks
  * hold fewer than four cells on average (a medium that differs from cell to cell: slower, meant for tests). */
 int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t blockWalk);
-/* The walk options in force: bit 0 layerSkip, bit 1 blockWalk. */
+/* The walk options in force: bit 0 layerSkip, bit 1 blockWalk, bit 2 the clear-air flight (asked for and possible on
+ * the grid and optics loaded). */
 int mcbrat_get_walk_mode(const mcbrat_ctx *ctx);
 
 /* The event threshold in use (after the first call of a domain: the one chosen by the trial launches). */
