@@ -297,6 +297,7 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
       std::vector<uint16_t> range((size_t)fbx * fby);
       std::vector<float> walk(e);
       std::fill(flyable.begin(), flyable.end(), 0);
+      bool anyRange = false;  // (a medium of one-extinction layers only has no use for flights: the runs do it in one step)
       for (int by = 0; by < fby; ++by)
         for (int bx = 0; bx < fbx; ++bx) {
           int lo = nz, hi = 0;
@@ -308,6 +309,7 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
             if (differs) { lo = std::min(lo, k); hi = k + 1; }
           }
           range[(size_t)bx + (size_t)fbx * by] = (uint16_t)(lo | (hi << 8));
+          anyRange = anyRange || hi > lo;
           for (int k = 0; k < nz; ++k) {
             if (k >= lo && k < hi) continue;
             flyable[k] = 1;
@@ -325,7 +327,7 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
           upload(c, &c->dBgVal, bgExt.data(), bgExt.size()))
         return 1;
       c->flyNbx = fbx; c->flyNby = fby;
-      c->flyBuilt = true;
+      c->flyBuilt = anyRange;
     }
   }
   {
@@ -580,6 +582,9 @@ int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   if constexpr (BLOCK == 256 && PRIV == 0 && !BRICK && !DBG && !INTEN) {
     // the large flux runs: dense grid in global memory, collision records (nc <= 2), layer-skipping walk, albedo
     // surface -- with the walk's spacing flags decided at compile time too (SPEC, mcbrat_kernels.hip)
+    if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk && !p.zRegularWalk)
+      return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 3>(c, p, lds, nBatches)
+                             : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 3>(c, p, lds, nBatches);
     if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk == p.zRegularWalk) {
       if (p.xyRegularWalk)
         return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 2>(c, p, lds, nBatches)

@@ -49,7 +49,7 @@ def _same(a, b):
         (a["nScatter"] == b["nScatter"]) & (np.abs(a["weight"] - b["weight"]) <= 1e-6)
 
 
-def blobs(nx=16, ny=12, nz=20, seed=5, background=0.0, albedo=0.0, regular=True, ssa=0.97, two=False):
+def blobs(nx=16, ny=12, nz=20, seed=5, background=0.0, albedo=0.0, regular=True, ssa=0.97, two=False, stretch_z=False):
     """A few box-shaped clouds of random extinction in a background that is the same in every cell of a layer (0: vacuum)."""
     rng = np.random.default_rng(seed)
     if regular:
@@ -58,6 +58,8 @@ def blobs(nx=16, ny=12, nz=20, seed=5, background=0.0, albedo=0.0, regular=True,
         xe = np.concatenate([[0.0], np.cumsum(0.04 * rng.uniform(0.7, 1.4, nx))])
         ye = np.concatenate([[0.0], np.cumsum(0.05 * rng.uniform(0.7, 1.4, ny))])
         ze = np.concatenate([[0.0], np.cumsum(0.03 * rng.uniform(0.6, 1.5, nz))])
+    if stretch_z:  # (equally spaced columns on stretched layers: an instantiation of its own, SPEC = 3 in mcbrat_kernels.hip)
+        ze = np.concatenate([[0.0], np.cumsum(0.02 + 0.02 * np.arange(nz) / max(nz - 1, 1))])
     bgp = background * np.exp(-np.arange(nz) / 8.0)
     ext = np.broadcast_to(bgp, (nx, ny, nz)).copy()
     for _ in range(int(rng.integers(2, 6))):
@@ -133,6 +135,20 @@ def test_stretched_grid(M):
     n = 30000
     case = blobs(nx=12, ny=8, nz=18, regular=False, background=0.01, albedo=0.3, seed=33)
     a, b = _run(M, case, 0.4, 250.0, 0, n), _run(M, case, 0.4, 250.0, 1, n)
+    assert b["mode"]["clearAirFlight"]
+    same = _same(b["fates"], a["fates"])
+    assert same.mean() > 0.985, same.mean()
+    assert same[a["fates"]["nScatter"] <= 2].mean() > 0.995
+    for k in ("legs", "crossings", "collisions", "topExits", "surfaceHits"):
+        assert abs(b["counters"][k] - a["counters"][k]) <= 3e-3 * a["counters"][k] + 5, (k, b["counters"][k], a["counters"][k])
+    assert np.all(np.abs(b["means"] - a["means"]) < 2e-3), (b["means"], a["means"])
+
+
+def test_equally_spaced_columns_on_stretched_layers(M):
+    """x and y step their face distances, z reads the edge table (the layout of a cloud scene on stretched layers)."""
+    n = 30000
+    case = blobs(nx=16, ny=16, nz=24, regular=True, stretch_z=True, background=0.01, albedo=0.0, seed=44, two=True)
+    a, b = _run(M, case, 0.5, 30.0, 0, n), _run(M, case, 0.5, 30.0, 1, n)
     assert b["mode"]["clearAirFlight"]
     same = _same(b["fates"], a["fates"])
     assert same.mean() > 0.985, same.mean()
