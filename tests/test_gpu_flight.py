@@ -158,6 +158,38 @@ def test_equally_spaced_columns_on_stretched_layers(M):
     assert np.all(np.abs(b["means"] - a["means"]) < 2e-3), (b["means"], a["means"])
 
 
+def test_thermal_source(M):
+    """Emission from the clouds, the haze and the surface (newPhotonStream_BBEmission, LW_flag > 0): photons start anywhere,
+    in marked cells too, in every direction; the emitting instantiations of the kernel with and without the flight."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    n = 40000
+    case = blobs(nx=16, ny=12, nz=20, background=0.05, albedo=0.1, seed=61, ssa=0.6)
+    nx, ny, nz = 16, 12, 20
+    case["temps"] = np.broadcast_to(290.0 - 3.0 * np.arange(nz), (nx, ny, nz)).copy()
+    case["sfc_temp"], case["lambda_um"] = 300.0, 10.0
+    out = {}
+    for skip in (0, 1):
+        dom = cases.product_domain(case)
+        w = M.new_Weights(nx, ny, nz)
+        M.emission_weighting(dom, w, case["sfc_temp"])
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True, LW_flag=1.0)
+        integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=skip)
+        photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 9)
+        fates = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+        mode = integ.walkMode()
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+        r = integ.reportResults()
+        out[skip] = (fates, np.array([r["meanFluxUp"], r["meanFluxDown"], r["meanFluxAbsorbed"]]), r["absorbedProfile"], mode)
+        integ.finalize()
+    assert out[1][3]["clearAirFlight"]
+    same = _same(out[1][0], out[0][0])
+    assert same.mean() > 0.985, same.mean()
+    assert np.all(np.abs(out[1][1] - out[0][1]) < 3e-3 * np.maximum(np.abs(out[0][1]), 0.05)), (out[1][1], out[0][1])
+    assert np.allclose(out[1][2], out[0][2], rtol=0.05, atol=0.02 * np.max(np.abs(out[0][2])))
+
+
 def test_column_count_not_a_multiple_of_four(M):
     """No brick columns, no flight: bitwise the moments of layerSkip = 2."""
     n = 20000
