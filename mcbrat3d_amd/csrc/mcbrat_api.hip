@@ -694,7 +694,10 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
     L.gridLds = false;
     L.lds = plan_launch_lds(c, L);
   }
-  if (L.fly) { p.fly = 1; p.flyNbx = c->flyNbx; p.flyNby = c->flyNby; p.extWalk = c->dExtWalk; }
+  if (L.fly) {
+    p.fly = 1; p.flyNbx = c->flyNbx; p.flyNby = c->flyNby; p.extWalk = c->dExtWalk;
+    p.flyInvBrickX = (float)(c->flyNbx / p.Lx); p.flyInvBrickY = (float)(c->flyNby / p.Ly);
+  }
   if (block_walk_applies(c, L)) return launch_block(c, p, L, debug, nBatches);
   // small domains (grid, tables and tallies in LDS): LDS holds two workgroups per CU, and two workgroups of 12 waves
   // (6 per SIMD, 80 VGPRs) beat two of 8 (4 per SIMD, no spills) by 10 % on the step cloud (640 and 896 lanes lose)

@@ -37,6 +37,7 @@ struct DevParams {
   // whose optical depth cannot be used up by the background alone steps from brick column to brick column
   int fly;
   int flyNbx, flyNby;             // brick columns along x / y (0: off)
+  float flyInvBrickX, flyInvBrickY;  // 1 / mean width of a brick column
   const uint16_t *flyRange;       // [flyNby][flyNbx] lo | hi << 8 (lo = nz, hi = 0: the brick column is background throughout)
   const float *extWalk;           // [nvox] what the photons' walk reads: ext, with the sign bit set in the cells outside their brick column's range (fly off: ext itself)
   const float *bgVal;             // [nz] background extinction of every layer (its most common value)

@@ -39,6 +39,13 @@ def main():
         case = cases.plane_parallel(ssa=a.ssa)
     elif a.case == "radar":
         case = cases.radar_like(n=a.n, nz=a.nz)
+    elif a.case == "overcast":  # a stratus deck: every column cloudy over the same layers, clear air (Rayleigh) above and below
+        case = cases.landsat_like(n=a.n, nz=a.nz, ssa_cloud=a.ssa)
+        e = case["components"][0]["ext"]
+        col = e.sum(axis=2, keepdims=True) / 12.0
+        e[:] = 0.0
+        e[:, :, 8:20] = col
+        case["components"][0]["ssa"] = np.where(e > 0, a.ssa, 0.0)
     else:
         case = cases.landsat_like(n=a.n, nz=a.nz, ssa_cloud=a.ssa)
     mu0, phi0 = (1.0, 0.0) if a.case in ("step", "plane") else (0.5, 30.0)
