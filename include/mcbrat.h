@@ -219,8 +219,9 @@ int mcbrat_set_surface_description(mcbrat_ctx *ctx, int32_t numX, int32_t numY, 
  * common ("background") extinction, a photon whose remaining optical depth cannot be used up by the background
  * between its height and the domain boundary steps from brick column to brick column, and takes its optical depth
  * from the background's vertical optical depth when that flight ends (at a cloud, or at the domain boundary).  Grids
- * whose column counts are multiples of four, at most 255 layers, fluxes only.  layerSkip = 2: the one-extinction layers
- * only, no flight.
+ * whose column counts are multiples of four, at most 255 layers, fluxes only, and a background whose vertical optical
+ * depth is at most 0.25 (in a haze most flights would be refused, and asking costs a turn in a queue).  layerSkip = 2:
+ * the one-extinction layers only, no flight; 3: flights whatever the optical depth of the background (tests).
  * blockWalk (default 1): domains whose optical grid is resident in LDS (I3RC step cloud, plane-parallel and other
  * small domains): the grid is cut into axis-aligned blocks of cells that carry one extinction value, and a leg goes
  * from block face to block face instead of from cell face to cell face; the cell of a collision or an exit is found

@@ -64,6 +64,8 @@ struct mcbrat_ctx {
   uint16_t *dFlyRange = nullptr;
   int flyNbx = 0, flyNby = 0;
   bool flyBuilt = false;
+  double flyDepth = 0.0;         // vertical optical depth of the background through the layers a flight can cross
+  double flightMaxDepth = 0.25;  // MCBRAT_FLIGHT_MAX_DEPTH: largest vertical optical depth of the background with which flights are used
   // block walk (mcbrat_blockwalk.hip)
   uint32_t *dBlockRec = nullptr;
   uint16_t *dBlockOf = nullptr;
@@ -327,7 +329,14 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
           upload(c, &c->dBgVal, bgExt.data(), bgExt.size()))
         return 1;
       c->flyNbx = fbx; c->flyNby = fby;
+      // A flight is only granted to a lane the background cannot stop before the domain boundary.  In a haze (vertical
+      // optical depth of the background not small against 1) most requests are refused, and asking costs a turn in the
+      // queue: measured -10 % on the 128x128x64 field in a haze of optical depth 2.3; Rayleigh air (0.02) is what the
+      // flight is for.  Between the two the limit is a guess (exp(-0.25 / mu) of the lanes may still fly).
+      double depth = 0.0;
+      for (int k = 0; k < nz; ++k) depth += flyable[k] ? (double)bgExt[k] * (c->ze[k + 1] - c->ze[k]) : 0.0;
       c->flyBuilt = anyRange;
+      c->flyDepth = depth;
     }
   }
   {
@@ -513,6 +522,11 @@ size_t per_layer_lds(int nz, int flyCols = 0) {
          (flyCols ? sizeof(float) * (size_t)((nz + 3) & ~3) + 2 * sizeof(float) * (size_t)flyCols + sizeof(uint16_t) * (size_t)((flyCols + 3) & ~3) : 0);
 }
 
+// clear-air flight: asked for (layerSkip 1: where the background is thin enough for it to pay; 3: regardless) and possible
+bool flight_wanted(const mcbrat_ctx *c) {
+  return c->flyBuilt && (c->layerSkip == 3 || (c->layerSkip == 1 && c->flyDepth <= c->flightMaxDepth));
+}
+
 struct LaunchPlan {
   bool tblLds, priv, brick, gridLds;
   bool fly;  // clear-air flight: dense grid in global memory, flux run, tables built, room in LDS
@@ -536,7 +550,7 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
   L.gridLds = L.priv && c->gridLdsMode != 0 && edges + bg + slab + grid + (L.tblLds ? tbl : 0) <= kLdsBudget;
   L.lds = edges + bg + (L.priv ? slab : 0) + (L.gridLds ? grid : 0) + (L.tblLds ? tbl : 0);
   const size_t flyLds = per_layer_lds(c->nz, c->flyNbx * c->flyNby) - bg;
-  L.fly = c->layerSkip == 1 && c->flyBuilt && !L.gridLds && !L.brick && c->nDir == 0 && L.lds + flyLds <= kLdsBudget;
+  L.fly = flight_wanted(c) && !L.gridLds && !L.brick && c->nDir == 0 && L.lds + flyLds <= kLdsBudget;
   if (L.fly) L.lds += flyLds;
   L.block = c->blockSize > 0 ? c->blockSize : (L.gridLds ? 768 : ((L.tblLds || L.priv) && L.lds > 16 * 1024 ? 512 : 256));
   return L;
@@ -771,6 +785,7 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (const char *e = getenv("MCBRAT_REGULAR_WALK")) c->regularWalk = atoi(e);
   if (const char *e = getenv("MCBRAT_LAYER_SKIP")) c->layerSkip = atoi(e);
   if (const char *e = getenv("MCBRAT_BLOCK_WALK")) c->blockWalk = atoi(e);
+  if (const char *e = getenv("MCBRAT_FLIGHT_MAX_DEPTH")) c->flightMaxDepth = atof(e);
   if (const char *e = getenv("MCBRAT_JUMP_THRESHOLD")) c->jumpThreshold = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_CROSS_THRESHOLD")) c->crossThreshold = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_RAY_DEFER")) c->rayDefer = atoi(e);
@@ -1191,7 +1206,7 @@ int mcbrat_set_surface_description(mcbrat_ctx *c, int32_t numX, int32_t numY, co
 
 int mcbrat_set_walk_options(mcbrat_ctx *c, int32_t layerSkip, int32_t blockWalk) {
   if (!c) return 1;
-  if (layerSkip >= 0) { if (layerSkip != c->layerSkip) c->tuned = false; c->layerSkip = layerSkip > 2 ? 1 : layerSkip; }
+  if (layerSkip >= 0) { if (layerSkip != c->layerSkip) c->tuned = false; c->layerSkip = layerSkip > 3 ? 1 : layerSkip; }
   if (blockWalk >= 0) { if (blockWalk != c->blockWalk) c->tuned = false; c->blockWalk = std::min(blockWalk, 2); }
   return 0;
 }
@@ -1235,7 +1250,7 @@ int mcbrat_frequency_distribution(mcbrat_ctx *c, uint64_t seed, uint64_t firstDr
   return 0;
 }
 
-int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0) | (c->layerSkip == 1 && c->flyBuilt ? 4 : 0)) : 0; }
+int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0) | (flight_wanted(c) ? 4 : 0)) : 0; }
 
 int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int64_t ppb, int32_t nBatches,
                                       int64_t *numPhotonsProcessed) {

@@ -46,6 +46,9 @@ def main():
         e[:] = 0.0
         e[:, :, 8:20] = col
         case["components"][0]["ssa"] = np.where(e > 0, a.ssa, 0.0)
+    elif a.case == "hazy":  # the cloud field in a haze one can collide in (the second component a hundred times the Rayleigh one)
+        case = cases.landsat_like(n=a.n, nz=a.nz, ssa_cloud=a.ssa)
+        case["components"][1]["ext"] = 100.0 * case["components"][1]["ext"]
     else:
         case = cases.landsat_like(n=a.n, nz=a.nz, ssa_cloud=a.ssa)
     mu0, phi0 = (1.0, 0.0) if a.case in ("step", "plane") else (0.5, 30.0)

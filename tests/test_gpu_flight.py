@@ -30,7 +30,8 @@ def _run(M, case, mu0, phi0, skip, n, rr=True, nsteps=9001, batches=2):
     dom = cases.product_domain(case)
     integ = M.new_Integrator(dom)
     integ.specifyParameters(minInverseTableSize=nsteps, useRayTracing=True, useRussianRoulette=rr)
-    integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=skip)  # (grid in global memory: where the flight lives)
+    # (grid in global memory: where the flight lives; 3 = flights whatever the optical depth of the background, 1 leaves them out in a haze)
+    integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=3 if skip == 1 else skip)
     photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
     rng = new_RandomNumberSequence(SEED)
     fates = integ.traceFates(dom, rng, photons, n)
@@ -174,7 +175,7 @@ def test_thermal_source(M):
         M.emission_weighting(dom, w, case["sfc_temp"])
         integ = M.new_Integrator(dom)
         integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True, LW_flag=1.0)
-        integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=skip)
+        integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=3 if skip == 1 else skip)
         photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 9)
         fates = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
         mode = integ.walkMode()
@@ -188,6 +189,26 @@ def test_thermal_source(M):
     assert same.mean() > 0.985, same.mean()
     assert np.all(np.abs(out[1][1] - out[0][1]) < 3e-3 * np.maximum(np.abs(out[0][1]), 0.05)), (out[1][1], out[0][1])
     assert np.allclose(out[1][2], out[0][2], rtol=0.05, atol=0.02 * np.max(np.abs(out[0][2])))
+
+
+def test_no_flights_in_a_haze_by_default(M):
+    """layerSkip = 1 leaves the flight out where the background's vertical optical depth is not small: bitwise layerSkip = 2."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    n = 20000
+    case = blobs(background=1.5, seed=21, two=True)
+    got = {}
+    for skip in (1, 2, 3):
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001)
+        integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=skip)
+        photons = M.new_PhotonStream(0.6, 120.0, numberOfPhotons=10 ** 9)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+        got[skip] = (integ.walkMode()["clearAirFlight"], integ.moments().copy())
+        integ.finalize()
+    assert not got[1][0] and not got[2][0] and got[3][0]
+    assert np.array_equal(got[1][1], got[2][1])
 
 
 def test_column_count_not_a_multiple_of_four(M):
