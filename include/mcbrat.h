@@ -267,6 +267,16 @@ int mcbrat_hybrid_phase_functions(int32_t nAngles, int32_t nEntries, const float
  * spans the whole periodic x / y axis.  Host arithmetic only.  Returns 1 for more than 65535 blocks / cells per axis. */
 int mcbrat_block_decomposition(int32_t nx, int32_t ny, int32_t nz, const float *extinction, uint16_t *blockOf,
                                uint32_t *blockRec, int32_t *nBlocks);
+/* The tables of the layer-skipping walk and the clear-air flight (mcbrat_set_walk_options, layerSkip), as the library
+ * builds them when the optics are set.  extinction[nx*ny*nz] (x fastest, float), zEdges[nz+1].  background[nz]: the
+ * most common extinction of every layer; range[(ny/4)*(nx/4)]: per brick column of 4 x 4 columns lo | hi << 8, the
+ * layers [lo, hi) that hold a cell differing from its layer's background (lo = nz, hi = 0: none); walk[nx*ny*nz]: the
+ * extinction with the sign bit set in every cell outside the range of its brick column; depth[nz+1]: vertical optical
+ * depth of the background below every face, over the layers a flight can cross; *flights: 1 when brick columns exist
+ * (nx, ny multiples of four, 2..255 layers) and some range is not empty.  range / walk are written only when brick
+ * columns exist.  Host arithmetic only. */
+int mcbrat_flight_tables(int32_t nx, int32_t ny, int32_t nz, const float *extinction, const double *zEdges,
+                         float *background, uint16_t *range, float *walk, double *depth, int32_t *flights);
 
 /* emission_weighting (src/emissionAndBroadBandWeights.f95:424-550): builds
  * voxelWeights (running CDF, x fastest), fracAtmsPower and the emitted flux. */

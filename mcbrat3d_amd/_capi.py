@@ -77,6 +77,7 @@ SYMBOLS = {
     "mcbrat_inverse_table_legendre": (C.c_int, [_i32, _vp, _i32, _vp]),
     "mcbrat_inverse_table_tabulated": (C.c_int, [_i32, _vp, _vp, _i32, _vp]),
     "mcbrat_block_decomposition": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mcbrat_flight_tables": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcbrat_emission_weighting": (C.c_int, [_i32] * 4 + [_vp] * 7 + [_d] * 4 + [_vp] * 3),
 }
 

@@ -263,20 +263,21 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
   const size_t ncol = (size_t)nx * ny, nvox = ncol * nz;
   std::vector<float> bgExt(nz), bgCum((size_t)nc * nz), bgSsa((size_t)nc * nz), layerExt(nz);
   std::vector<uint16_t> bgPfi((size_t)nc * nz);
-  std::vector<float> layer(ncol);
+  // the layers' background extinction, the brick columns' cloud ranges, the walk's marked copy of the extinction and the
+  // vertical optical depth of the background (layer-skipping walk, clear-air flight): mcbrat_flight_tables, mcbrat_host.cpp
+  const bool bricks4 = nx % 4 == 0 && ny % 4 == 0 && nz >= 2 && nz <= 255;
+  std::vector<uint16_t> range(bricks4 ? (size_t)(nx / 4) * (ny / 4) : 0);
+  std::vector<float> walk(bricks4 ? nvox : 0);
+  std::vector<double> runT(nz + 1, 0.0);
+  int32_t flights = 0;
+  if (mcbrat_flight_tables(nx, ny, nz, e.data(), c->ze.data(), bgExt.data(), bricks4 ? range.data() : nullptr,
+                           bricks4 ? walk.data() : nullptr, runT.data(), &flights))
+    return fail(c, "getOpticalPropertiesByComponent: could not build the tables of the walk.");
   for (int k = 0; k < nz; ++k) {
-    std::copy(e.begin() + ncol * k, e.begin() + ncol * (k + 1), layer.begin());
-    std::sort(layer.begin(), layer.end());
-    float best = layer[0];
-    size_t bestRun = 0;
-    for (size_t i = 0; i < ncol;) {  // mode of the layer
-      size_t j = i;
-      while (j < ncol && layer[j] == layer[i]) ++j;
-      if (j - i > bestRun) { bestRun = j - i; best = layer[i]; }
-      i = j;
-    }
-    bgExt[k] = best;
-    layerExt[k] = bestRun == ncol ? best : -1.0f;  // a layer of one extinction value needs no gather in the walk
+    const float best = bgExt[k];
+    bool uniform = true;
+    for (size_t v = ncol * k; v < ncol * (k + 1) && uniform; ++v) uniform = e[v] == best;
+    layerExt[k] = uniform ? best : -1.0f;  // a layer of one extinction value needs no gather in the walk
     size_t rep = ncol * k;
     while (e[rep] != best) ++rep;  // a representative background cell of this layer
     for (int q = 0; q < nc; ++q) {
@@ -286,69 +287,26 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
     }
   }
   if (upload(c, &c->dLayerExt, layerExt.data(), layerExt.size())) return 1;
-  std::vector<char> flyable(nz, 0);  // layers in which some brick column lies outside its range (clear-air flight)
-  {
-    // clear-air flight: per brick column (4 x 4 columns) the layers [lo, hi) that hold a cell whose extinction differs
-    // from its layer's background; the walk's copy of the extinction carries the sign bit in every cell outside the
-    // range of its brick column (such a cell holds its layer's background value by construction)
-    c->flyBuilt = false;
-    c->flyNbx = c->flyNby = 0;
-    for (int k = 0; k < nz; ++k) flyable[k] = layerExt[k] >= 0.f ? 1 : 0;
-    if (nx % 4 == 0 && ny % 4 == 0 && nz >= 2 && nz <= 255) {
-      const int fbx = nx / 4, fby = ny / 4;
-      std::vector<uint16_t> range((size_t)fbx * fby);
-      std::vector<float> walk(e);
-      std::fill(flyable.begin(), flyable.end(), 0);
-      bool anyRange = false;  // (a medium of one-extinction layers only has no use for flights: the runs do it in one step)
-      for (int by = 0; by < fby; ++by)
-        for (int bx = 0; bx < fbx; ++bx) {
-          int lo = nz, hi = 0;
-          for (int k = 0; k < nz; ++k) {
-            bool differs = false;
-            for (int j = by * 4; j < by * 4 + 4 && !differs; ++j)
-              for (int i = bx * 4; i < bx * 4 + 4 && !differs; ++i)
-                differs = e[(size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k)] != bgExt[k];
-            if (differs) { lo = std::min(lo, k); hi = k + 1; }
-          }
-          range[(size_t)bx + (size_t)fbx * by] = (uint16_t)(lo | (hi << 8));
-          anyRange = anyRange || hi > lo;
-          for (int k = 0; k < nz; ++k) {
-            if (k >= lo && k < hi) continue;
-            flyable[k] = 1;
-            for (int j = by * 4; j < by * 4 + 4; ++j)
-              for (int i = bx * 4; i < bx * 4 + 4; ++i) {
-                float &w = walk[(size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k)];
-                uint32_t u;
-                std::memcpy(&u, &w, 4);
-                u |= 0x80000000u;
-                std::memcpy(&w, &u, 4);
-              }
-          }
-        }
-      if (upload(c, &c->dFlyRange, range.data(), range.size()) || upload(c, &c->dExtWalk, walk.data(), walk.size()) ||
-          upload(c, &c->dBgVal, bgExt.data(), bgExt.size()))
-        return 1;
-      c->flyNbx = fbx; c->flyNby = fby;
-      // A flight is only granted to a lane the background cannot stop before the domain boundary.  In a haze (vertical
-      // optical depth of the background not small against 1) most requests are refused, and asking costs a turn in the
-      // queue: measured -10 % on the 128x128x64 field in a haze of optical depth 2.3; Rayleigh air (0.02) is what the
-      // flight is for.  Between the two the limit is a guess (exp(-0.25 / mu) of the lanes may still fly).
-      double depth = 0.0;
-      for (int k = 0; k < nz; ++k) depth += flyable[k] ? (double)bgExt[k] * (c->ze[k + 1] - c->ze[k]) : 0.0;
-      c->flyBuilt = anyRange;
-      c->flyDepth = depth;
-    }
+  c->flyBuilt = false;
+  c->flyNbx = c->flyNby = 0;
+  if (bricks4) {
+    if (upload(c, &c->dFlyRange, range.data(), range.size()) || upload(c, &c->dExtWalk, walk.data(), walk.size()) ||
+        upload(c, &c->dBgVal, bgExt.data(), bgExt.size()))
+      return 1;
+    c->flyNbx = nx / 4; c->flyNby = ny / 4;
+    // A flight is only granted to a lane the background cannot stop before the domain boundary.  In a haze (vertical
+    // optical depth of the background not small against 1) most requests are refused, and asking costs a turn in the
+    // queue: measured -10 % on the 128x128x64 field in a haze of optical depth 2.3; Rayleigh air (0.02) is what the
+    // flight is for.  Between the two the limit is a guess (exp(-0.25 / mu) of the lanes may still fly): flight_wanted.
+    c->flyBuilt = flights != 0;
+    c->flyDepth = runT[nz];
   }
   {
     // runs of consecutive one-extinction layers (layer-skipping walk): for layer k the face where its run ends
-    // upwards / downwards, and the vertical optical depth of such layers below every face
+    // upwards / downwards.  (runT: inside a run of one-extinction layers its differences are the run's own; a layer no
+    // flight can cross adds nothing to it -- differences across such a layer are only used as the bound on what the
+    // background can take from a lane before its flight ends.)
     std::vector<int> run(nz, 0);
-    std::vector<double> runT(nz + 1, 0.0);
-    // (of the background extinction of every layer a flight can pass through -- one in which some brick column lies
-    // outside its range; the one-extinction layers are among them, and inside a run of those the differences are the
-    // run's own.  A layer no flight can cross adds nothing: differences across it are only used as the bound on what
-    // the background can take from a lane before its flight ends.)
-    for (int k = 0; k < nz; ++k) runT[k + 1] = runT[k] + (flyable[k] ? (double)bgExt[k] * (c->ze[k + 1] - c->ze[k]) : 0.0);
     for (int k = 0; k < nz; ++k) {
       int up = k + 1, down = k;
       while (up < nz && layerExt[up] >= 0.f) ++up;

@@ -4,6 +4,7 @@
 // src/emissionAndBroadBandWeights.f95); the GPU kernels only consume their outputs.
 // Arithmetic kinds follow the reference: `real` -> float, `real(8)` -> double, evaluated
 // in the written order (build with -ffp-contract=off).
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -384,5 +385,78 @@ extern "C" int mcbrat_block_decomposition(int32_t nx, int32_t ny, int32_t nz, co
       }
   for (size_t v = 0; v < nvox; ++v) blockOf[v] = (uint16_t)of[v];
   *nBlocks = (int32_t)nb;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tables of the layer-skipping walk and the clear-air flight (mcbrat_kernels.hip).
+//   background[nz]        the most common extinction of every layer (ties: the smallest such value)
+//   range[(ny/4)*(nx/4)]  per brick column (4 x 4 columns) lo | hi << 8: the layers [lo, hi) that hold a cell whose
+//                         extinction differs from its layer's background (lo = nz, hi = 0: none)
+//   walk[nx*ny*nz]        the extinction, with the sign bit set in every cell outside the range of its brick column
+//                         (such a cell holds its layer's background value)
+//   depth[nz+1]           vertical optical depth of the background below every face, over the layers a flight can
+//                         cross: those in which some brick column lies outside its range (a layer of one extinction
+//                         value is one of them); without brick columns: the one-extinction layers
+//   *flights              1 when brick columns exist (column counts multiples of four, 2..255 layers) and some range
+//                         is not empty (a medium of one-extinction layers only is served by the runs alone)
+// range and walk are only written when brick columns exist (they may be null otherwise).  Host arithmetic only.
+// ------------------------------------------------------------------------------------------------
+extern "C" int mcbrat_flight_tables(int32_t nx, int32_t ny, int32_t nz, const float *ext, const double *zEdges,
+                                    float *background, uint16_t *range, float *walk, double *depth, int32_t *flights) {
+  if (nx < 1 || ny < 1 || nz < 1 || !ext || !zEdges || !background || !depth || !flights) return 1;
+  const size_t ncol = (size_t)nx * ny;
+  std::vector<float> layer(ncol);
+  std::vector<char> flyable(nz, 0);
+  for (int k = 0; k < nz; ++k) {
+    std::copy(ext + ncol * k, ext + ncol * (k + 1), layer.begin());
+    std::sort(layer.begin(), layer.end());
+    float best = layer[0];
+    size_t bestRun = 0;
+    for (size_t i = 0; i < ncol;) {  // mode of the layer
+      size_t j = i;
+      while (j < ncol && layer[j] == layer[i]) ++j;
+      if (j - i > bestRun) { bestRun = j - i; best = layer[i]; }
+      i = j;
+    }
+    background[k] = best;
+    flyable[k] = bestRun == ncol ? 1 : 0;
+  }
+  *flights = 0;
+  if (nx % 4 == 0 && ny % 4 == 0 && nz >= 2 && nz <= 255) {
+    if (!range || !walk) return 1;
+    const int fbx = nx / 4, fby = ny / 4;
+    std::copy(ext, ext + ncol * nz, walk);
+    std::fill(flyable.begin(), flyable.end(), 0);
+    bool anyRange = false;
+    for (int by = 0; by < fby; ++by)
+      for (int bx = 0; bx < fbx; ++bx) {
+        int lo = nz, hi = 0;
+        for (int k = 0; k < nz; ++k) {
+          bool differs = false;
+          for (int j = by * 4; j < by * 4 + 4 && !differs; ++j)
+            for (int i = bx * 4; i < bx * 4 + 4 && !differs; ++i)
+              differs = ext[(size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k)] != background[k];
+          if (differs) { lo = std::min(lo, k); hi = k + 1; }
+        }
+        range[(size_t)bx + (size_t)fbx * by] = (uint16_t)(lo | (hi << 8));
+        anyRange = anyRange || hi > lo;
+        for (int k = 0; k < nz; ++k) {
+          if (k >= lo && k < hi) continue;
+          flyable[k] = 1;
+          for (int j = by * 4; j < by * 4 + 4; ++j)
+            for (int i = bx * 4; i < bx * 4 + 4; ++i) {
+              float &w = walk[(size_t)i + (size_t)nx * ((size_t)j + (size_t)ny * k)];
+              uint32_t u;
+              std::memcpy(&u, &w, 4);
+              u |= 0x80000000u;
+              std::memcpy(&w, &u, 4);
+            }
+        }
+      }
+    *flights = anyRange ? 1 : 0;
+  }
+  depth[0] = 0.0;
+  for (int k = 0; k < nz; ++k) depth[k + 1] = depth[k] + (flyable[k] ? (double)background[k] * (zEdges[k + 1] - zEdges[k]) : 0.0);
   return 0;
 }
