@@ -220,7 +220,7 @@ int mcbrat_set_surface_description(mcbrat_ctx *ctx, int32_t numX, int32_t numY, 
  * between its height and the domain boundary steps from brick column to brick column, and takes its optical depth
  * from the background's vertical optical depth when that flight ends (at a cloud, or at the domain boundary).  Grids
  * whose column counts are multiples of four, at most 255 layers, fluxes only, and a background whose vertical optical
- * depth is at most 0.25 (in a haze most flights would be refused, and asking costs a turn in a queue).  layerSkip = 2:
+ * depth is at most 0.5 (in a haze most flights would be refused, and asking costs a turn in a queue).  layerSkip = 2:
  * the one-extinction layers only, no flight; 3: flights whatever the optical depth of the background (tests).
  * blockWalk (default 1): domains whose optical grid is resident in LDS (I3RC step cloud, plane-parallel and other
  * small domains): the grid is cut into axis-aligned blocks of cells that carry one extinction value, and a leg goes

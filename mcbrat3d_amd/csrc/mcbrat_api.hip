@@ -65,7 +65,7 @@ struct mcbrat_ctx {
   int flyNbx = 0, flyNby = 0;
   bool flyBuilt = false;
   double flyDepth = 0.0;         // vertical optical depth of the background through the layers a flight can cross
-  double flightMaxDepth = 0.25;  // MCBRAT_FLIGHT_MAX_DEPTH: largest vertical optical depth of the background with which flights are used
+  double flightMaxDepth = 0.5;   // MCBRAT_FLIGHT_MAX_DEPTH: largest vertical optical depth of the background with which flights are used
   // block walk (mcbrat_blockwalk.hip)
   uint32_t *dBlockRec = nullptr;
   uint16_t *dBlockOf = nullptr;
@@ -297,7 +297,8 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
     // A flight is only granted to a lane the background cannot stop before the domain boundary.  In a haze (vertical
     // optical depth of the background not small against 1) most requests are refused, and asking costs a turn in the
     // queue: measured -10 % on the 128x128x64 field in a haze of optical depth 2.3; Rayleigh air (0.02) is what the
-    // flight is for.  Between the two the limit is a guess (exp(-0.25 / mu) of the lanes may still fly): flight_wanted.
+    // flight is for.  In between (same field, 5 / 10 / 20 / 40 times the Rayleigh extinction = 0.12 / 0.23 / 0.46 / 0.92):
+    // +13 / +8 / +2 / -5 %, so the limit is 0.5 (flight_wanted).
     c->flyBuilt = flights != 0;
     c->flyDepth = runT[nz];
   }

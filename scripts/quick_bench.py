@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--bw", type=int, nargs="*", default=[-1], help="block walk (LDS-resident grids): -1 default, 0 off, 1 on")
     ap.add_argument("--n", type=int, default=128, help="landsat / radar: columns per side")
     ap.add_argument("--nz", type=int, default=64)
+    ap.add_argument("--haze", type=float, default=100.0, help="case hazy: the Rayleigh component times this (optical depth 0.023 x haze)")
     a = ap.parse_args()
     import mcbrat3d_amd as M
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
@@ -48,7 +49,7 @@ def main():
         case["components"][0]["ssa"] = np.where(e > 0, a.ssa, 0.0)
     elif a.case == "hazy":  # the cloud field in a haze one can collide in (the second component a hundred times the Rayleigh one)
         case = cases.landsat_like(n=a.n, nz=a.nz, ssa_cloud=a.ssa)
-        case["components"][1]["ext"] = 100.0 * case["components"][1]["ext"]
+        case["components"][1]["ext"] = a.haze * case["components"][1]["ext"]
     else:
         case = cases.landsat_like(n=a.n, nz=a.nz, ssa_cloud=a.ssa)
     mu0, phi0 = (1.0, 0.0) if a.case in ("step", "plane") else (0.5, 30.0)
