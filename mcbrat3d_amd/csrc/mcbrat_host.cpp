@@ -396,8 +396,8 @@ extern "C" int mcbrat_block_decomposition(int32_t nx, int32_t ny, int32_t nz, co
 //   walk[nx*ny*nz]        the extinction, with the sign bit set in every cell outside the range of its brick column
 //                         (such a cell holds its layer's background value)
 //   depth[nz+1]           vertical optical depth of the background below every face, over the layers a flight can
-//                         cross: those in which some brick column lies outside its range (a layer of one extinction
-//                         value is one of them); without brick columns: the one-extinction layers
+//                         cross -- those in which some brick column lies outside its range -- and the layers of one
+//                         extinction value (runs of the layer-skipping walk); without brick columns: the latter only
 //   *flights              1 when brick columns exist (column counts multiples of four, 2..255 layers) and some range
 //                         is not empty (a medium of one-extinction layers only is served by the runs alone)
 // range and walk are only written when brick columns exist (they may be null otherwise).  Host arithmetic only.
@@ -407,7 +407,7 @@ extern "C" int mcbrat_flight_tables(int32_t nx, int32_t ny, int32_t nz, const fl
   if (nx < 1 || ny < 1 || nz < 1 || !ext || !zEdges || !background || !depth || !flights) return 1;
   const size_t ncol = (size_t)nx * ny;
   std::vector<float> layer(ncol);
-  std::vector<char> flyable(nz, 0);
+  std::vector<char> flyable(nz, 0), uniform(nz, 0);
   for (int k = 0; k < nz; ++k) {
     std::copy(ext + ncol * k, ext + ncol * (k + 1), layer.begin());
     std::sort(layer.begin(), layer.end());
@@ -420,7 +420,8 @@ extern "C" int mcbrat_flight_tables(int32_t nx, int32_t ny, int32_t nz, const fl
       i = j;
     }
     background[k] = best;
-    flyable[k] = bestRun == ncol ? 1 : 0;
+    uniform[k] = bestRun == ncol ? 1 : 0;
+    flyable[k] = uniform[k];
   }
   *flights = 0;
   if (nx % 4 == 0 && ny % 4 == 0 && nz >= 2 && nz <= 255) {
@@ -456,7 +457,9 @@ extern "C" int mcbrat_flight_tables(int32_t nx, int32_t ny, int32_t nz, const fl
       }
     *flights = anyRange ? 1 : 0;
   }
+  // (a layer of one extinction value always counts: the runs of the layer-skipping walk take their optical depth from
+  // this table, also where such a layer lies between two cloud decks, inside the range of every brick column)
   depth[0] = 0.0;
-  for (int k = 0; k < nz; ++k) depth[k + 1] = depth[k] + (flyable[k] ? (double)background[k] * (zEdges[k + 1] - zEdges[k]) : 0.0);
+  for (int k = 0; k < nz; ++k) depth[k + 1] = depth[k] + ((flyable[k] || uniform[k]) ? (double)background[k] * (zEdges[k + 1] - zEdges[k]) : 0.0);
   return 0;
 }

@@ -67,8 +67,9 @@ def check(ext, ze):
             assert np.array_equal(np.abs(w), e)
             assert np.all(e[:, :, ~inside] == bg[None, None, ~inside]), "a marked cell does not hold the background"
     assert flights == int(any_range)
-    assert np.all(flyable[uniform])  # (a layer of one extinction value is outside every range)
-    assert np.allclose(depth, np.concatenate([[0.0], np.cumsum(np.where(flyable, bg.astype(np.float64) * dz, 0.0))]), rtol=1e-12, atol=0)
+    # (a layer of one extinction value counts even between two cloud decks, inside every range: the runs of the
+    # layer-skipping walk take their optical depth from this table)
+    assert np.allclose(depth, np.concatenate([[0.0], np.cumsum(np.where(flyable | uniform, bg.astype(np.float64) * dz, 0.0))]), rtol=1e-12, atol=0)
 
 
 @settings(max_examples=60, deadline=None)
@@ -90,6 +91,11 @@ def test_workloads_and_edge_cases():
     check(tot, c["ze"])
     bg, lo, hi, walk, depth, flights = tables(tot.astype(np.float32), c["ze"])
     assert flights == 1 and lo.min() == 8  # (the cloud base of the generator)
+    # two cloud decks with a layer of one extinction value between them, inside the range of every brick column
+    e = np.zeros((4, 4, 5)); e[:, :, 0] = np.arange(16).reshape(4, 4) + 1.0; e[:, :, 4] = e[:, :, 0]; e[:, :, 2] = 3.0
+    bgd, lo, hi, walk, depth, flights = tables(e.astype(np.float32), np.linspace(0.0, 1.0, 6))
+    assert (lo[0, 0], hi[0, 0]) == (0, 5) and depth[3] - depth[2] == pytest.approx(3.0 * 0.2)
+    check(e, np.linspace(0.0, 1.0, 6))
     # a homogeneous medium: every brick column is background throughout, no flights
     e = np.full((8, 4, 5), 2.5)
     check(e, np.linspace(0.0, 1.0, 6))

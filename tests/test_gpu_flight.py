@@ -159,6 +159,30 @@ def test_equally_spaced_columns_on_stretched_layers(M):
     assert np.all(np.abs(b["means"] - a["means"]) < 2e-3), (b["means"], a["means"])
 
 
+def test_layer_of_one_extinction_between_two_cloud_decks(M):
+    """A hazy layer with one extinction value between two broken cloud decks lies inside the range of every brick column:
+    no flight crosses it, the runs of the layer-skipping walk do, and they take its optical depth from the same table."""
+    n = 30000
+    rng = np.random.default_rng(77)
+    nx, ny, nz = 16, 8, 14
+    ext = np.zeros((nx, ny, nz))
+    ext[:, :, 2:4] = rng.uniform(3.0, 30.0, (nx, ny, 1)) * (rng.random((nx, ny, 1)) < 0.8)
+    ext[:, :, 9:11] = rng.uniform(3.0, 30.0, (nx, ny, 1)) * (rng.random((nx, ny, 1)) < 0.8)
+    ext[:, :, 5:8] = 4.0  # the layers in between: one value each, optical depth 0.4 each
+    case = dict(name="decks", xe=0.0625 * np.arange(nx + 1), ye=0.0625 * np.arange(ny + 1), ze=0.1 * np.arange(nz + 1), albedo=0.2,
+                components=[dict(ext=ext, ssa=np.where(ext > 0, 0.95, 0.0), pfIndex=np.ones(ext.shape, np.int32),
+                                 legendre=[cases.hg_legendre(0.8, 32)])])
+    a = _run(M, case, 0.6, 40.0, 0, n)
+    for skip in (2, 1):
+        b = _run(M, case, 0.6, 40.0, skip, n)
+        same = _same(b["fates"], a["fates"])
+        assert same.mean() > 0.985, (skip, same.mean())
+        for k in ("legs", "crossings", "collisions", "topExits", "surfaceHits"):
+            assert abs(b["counters"][k] - a["counters"][k]) <= 3e-3 * a["counters"][k] + 5, (skip, k, b["counters"][k], a["counters"][k])
+        assert np.all(np.abs(b["means"] - a["means"]) < 2e-3), (skip, b["means"], a["means"])
+    assert b["mode"]["clearAirFlight"]
+
+
 def test_thermal_source(M):
     """Emission from the clouds, the haze and the surface (newPhotonStream_BBEmission, LW_flag > 0): photons start anywhere,
     in marked cells too, in every direction; the emitting instantiations of the kernel with and without the flight."""
