@@ -10,6 +10,8 @@ layers only; 0: face by face) and against the oracle on the same Philox streams,
 cases the flight has to get right: vacuum background (the mark is a sign bit on 0.0), a background thick enough to
 collide in, periodic wraps at a grazing sun, a reflecting surface under the clouds, equally spaced and stretched
 grids, grids whose column count is not a multiple of four (no flight)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -17,6 +19,7 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 SEED = 90210
+FUZZ = int(os.environ.get("MCBRAT_FLIGHT_FUZZ", "12"))  # seeds of the random differential tests (raise it for a soak run)
 
 
 @pytest.fixture(scope="module")
@@ -73,7 +76,7 @@ def blobs(nx=16, ny=12, nz=20, seed=5, background=0.0, albedo=0.0, regular=True,
     if two:
         comps.append(dict(ext=0.02 * np.exp(-np.arange(nz) / 6.0), ssa=np.ones(nz), pfIndex=np.ones(nz, np.int32),
                           legendre=[np.array([0.0, 0.1], np.float32)]))
-    return dict(name="blobs%d" % seed, xe=xe, ye=ye, ze=ze, albedo=albedo, components=comps)
+    return dict(name="blobs%d" % seed, xe=xe, ye=ye, ze=ze, albedo=albedo, components=comps, regular=regular)
 
 
 def test_cloud_field_against_walk_without_flight_and_oracle(M):
@@ -245,7 +248,7 @@ def test_column_count_not_a_multiple_of_four(M):
     assert np.array_equal(b["means"], a["means"])
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(FUZZ))
 def test_random_fields_against_face_by_face_walk(M, seed):
     """Differential test: random box clouds, random background (vacuum, thin, thick), equal or stretched spacing, one or two
     components, random sun and surface, column counts that are multiples of four."""
@@ -262,6 +265,51 @@ def test_random_fields_against_face_by_face_walk(M, seed):
     assert same.mean() > 0.97, (case["name"], nx, ny, nz, same.mean())
     assert same[a["fates"]["nScatter"] <= 2].mean() > 0.995
     assert np.all(np.abs(b["means"] - a["means"]) < 4e-3), (b["means"], a["means"])
-    alb = case["albedo"]
-    # (Russian roulette in an absorbing haze restores weights to 1: conservation holds in the mean, with that variance)
-    assert abs(b["means"][0] + b["means"][2] + (1.0 - alb) * b["means"][1] - 1.0) < 6.0 / np.sqrt(n)
+    # (conservation in terms of the domain MEANS needs columns of equal area: reportResults :881-884 averages the
+    # per-column fluxes without area weights)
+    if case["regular"]:
+        assert abs(b["means"][0] + b["means"][2] + (1.0 - case["albedo"]) * b["means"][1] - 1.0) < 4.0 / np.sqrt(n)
+
+
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_layerings_against_face_by_face_walk(M, seed):
+    """Differential test on random LAYERINGS: every layer is, at random, vacuum, a haze of one extinction value, broken
+    cloud over a clear or hazy background (so that cloud decks alternate with layers of one value inside the brick columns'
+    ranges), or different in every cell -- the top and bottom layers included."""
+    rng = np.random.default_rng(9100 + seed)
+    nx, ny, nz = 4 * int(rng.integers(1, 5)), 4 * int(rng.integers(1, 4)), int(rng.integers(3, 16))
+    ext = np.zeros((nx, ny, nz))
+    for k in range(nz):
+        kind = rng.choice(["vacuum", "haze", "broken", "broken", "random"])
+        if kind == "haze":
+            ext[:, :, k] = rng.choice([0.02, 0.5, 4.0])
+        elif kind == "broken":
+            bgv = rng.choice([0.0, 0.0, 0.05, 1.0])
+            cloudy = rng.random((nx, ny)) < rng.uniform(0.05, 0.9)
+            if rng.random() < 0.5:  # (whole brick columns at a time: ranges that differ between brick columns)
+                cloudy = np.kron(rng.random((nx // 4, ny // 4)) < 0.5, np.ones((4, 4), bool))
+            ext[:, :, k] = np.where(cloudy, rng.uniform(3.0, 40.0, (nx, ny)), bgv)
+        elif kind == "random":
+            ext[:, :, k] = rng.uniform(0.0, 20.0, (nx, ny))
+    regular = bool(rng.random() < 0.5)
+    if regular:
+        xe, ye, ze = 0.0625 * np.arange(nx + 1), 0.0625 * np.arange(ny + 1), 0.03125 * np.arange(nz + 1)
+    else:
+        xe = np.concatenate([[0.0], np.cumsum(0.04 * rng.uniform(0.7, 1.4, nx))])
+        ye = np.concatenate([[0.0], np.cumsum(0.05 * rng.uniform(0.7, 1.4, ny))])
+        ze = np.concatenate([[0.0], np.cumsum(0.03 * rng.uniform(0.6, 1.5, nz))])
+    alb = float(rng.choice([0.0, 0.4]))
+    case = dict(name="layering%d" % seed, xe=xe, ye=ye, ze=ze, albedo=alb,
+                components=[dict(ext=ext, ssa=np.where(ext > 0, float(rng.uniform(0.8, 1.0)), 0.0), pfIndex=np.ones(ext.shape, np.int32),
+                                 legendre=[cases.hg_legendre(float(rng.uniform(0.0, 0.9)), 24)])])
+    mu0, phi0 = float(rng.choice([1.0, rng.uniform(0.05, 1.0)])), float(rng.uniform(0.0, 360.0))
+    n = 20000
+    a, b = _run(M, case, mu0, phi0, 0, n, batches=1), _run(M, case, mu0, phi0, 1, n, batches=1)
+    same = _same(b["fates"], a["fates"])
+    assert same.mean() > 0.97, (case["name"], nx, ny, nz, same.mean())
+    assert same[a["fates"]["nScatter"] <= 2].mean() > 0.995
+    for k in ("legs", "collisions", "topExits", "surfaceHits"):
+        assert abs(b["counters"][k] - a["counters"][k]) <= 5e-3 * a["counters"][k] + 10, (k, b["counters"][k], a["counters"][k])
+    assert np.all(np.abs(b["means"] - a["means"]) < 4e-3), (b["means"], a["means"])
+    if regular:  # (see test_random_fields_against_face_by_face_walk)
+        assert abs(b["means"][0] + b["means"][2] + (1.0 - alb) * b["means"][1] - 1.0) < 4.0 / np.sqrt(n)
