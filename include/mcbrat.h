@@ -230,7 +230,8 @@ int mcbrat_set_surface_description(mcbrat_ctx *ctx, int32_t numX, int32_t numY, 
  * hold fewer than four cells on average (a medium that differs from cell to cell: slower, meant for tests). */
 int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t blockWalk);
 /* The walk options in force: bit 0 layerSkip, bit 1 blockWalk, bit 2 the clear-air flight (asked for and possible on
- * the grid and optics loaded). */
+ * the grid and optics loaded: brick columns exist, the background is thin enough or layerSkip = 3, no radiance
+ * directions; a grid small enough to live in LDS does not use it either). */
 int mcbrat_get_walk_mode(const mcbrat_ctx *ctx);
 
 /* The event threshold in use (after the first call of a domain: the one chosen by the trial launches). */

@@ -1209,7 +1209,7 @@ int mcbrat_frequency_distribution(mcbrat_ctx *c, uint64_t seed, uint64_t firstDr
   return 0;
 }
 
-int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0) | (flight_wanted(c) ? 4 : 0)) : 0; }
+int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0) | ((flight_wanted(c) && c->nDir == 0 && !use_bricks(c)) ? 4 : 0)) : 0; }
 
 int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int64_t ppb, int32_t nBatches,
                                       int64_t *numPhotonsProcessed) {
