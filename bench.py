@@ -476,6 +476,7 @@ def main():
         sync()
 
     out = None
+    thr_timed = integ.eventThreshold()  # (a later, larger call -- the parity run -- may trigger the trial launches and choose another)
     if rank == 0:
         # the moment arrays now hold the last step: world * per_step photons, reduced over ranks
         stats = driver.statistics(driver.unpack_moments(moments.cpu().numpy(), nx, ny, nz))
@@ -488,7 +489,8 @@ def main():
             photons.currentPhoton = 1
             integ.computeRadiativeTransfer(dom, rng, photons, ppb, a.parity_photons // ppb)
             stats = driver.statistics(driver.unpack_moments(integ.moments(), nx, ny, nz))
-        # untimed: event counters (instrumented kernel) on one step's worth of photons
+        # untimed: event counters (instrumented kernel) on one step's worth of photons, at the timed steps' event threshold
+        integ.setTuning(eventThreshold=thr_timed)
         integ.resetMoments()
         integ.enableCounters(True)
         rng.nextPhotonId = 0
@@ -509,7 +511,7 @@ def main():
                        **({"rehearsal": "gloo, all ranks on cuda:0 -- not a measurement"} if rehearse else {}),
                        "photons_in_reduced_moments_last_step": reduced_photons,
                        "pipelined_steps": bool(a.pipeline), "pipelined_photons_per_s_untimed_extra": pipelined_rate,
-                       "event_threshold": integ.eventThreshold(),
+                       "event_threshold": thr_timed,
                        "walk": integ.walkMode()},
             "roofline": roofline_block(a.workload, cnt, per_step, nc, launch_ms, a.pipeline, integ.walkMode()["blockWalk"]),
         }

@@ -124,7 +124,7 @@ struct mcbrat_ctx {
   int maxBatchesInFlight = 0;  // 0: bounded by memory
   int privMode = 1;            // 1: LDS-private tallies when the slab fits, 0: always global atomics
   int blockSize = 0;           // 0: chosen by plan_launch
-  unsigned long long tuneTrialPhotons = 1ull << 24;  // MCBRAT_TUNE_PHOTONS
+  unsigned long long tuneTrialPhotons = 1ull << 26;  // MCBRAT_TUNE_PHOTONS
   int regularWalk = 1;         // equally spaced grids: incremental face distances (MCBRAT_REGULAR_WALK=0 turns it off)
   int gridLdsMode = 1;         // stage the optical grid in LDS when it fits (private-tally mode)
   int rayShort = 0, rayPassIters = 0, rayPassAt = 0;  // 0: chosen in launch_trace_b (MCBRAT_RAY_SHORT, MCBRAT_RAY_PASS_ITERS, MCBRAT_RAY_PASS_AT)
@@ -693,15 +693,16 @@ int check_ready(mcbrat_ctx *c) {
 // Times short trial launches at a few event thresholds and keeps the fastest.  The best value
 // depends on how many voxel faces a leg crosses (step cloud ~3, 128x128x64 cloud field ~14).
 int autotune(mcbrat_ctx *c, DevParams p, unsigned long long ppb, int nBatches) {
-  // about 64 photons per resident lane: with fewer the synchronised start and the drain of the launch dominate
-  // and favour too low a threshold
+  // about 170 photons per resident lane (6.7e7): with fewer the synchronised start and the drain of the launch favour too
+  // low a threshold -- measured on the two 128x128x64 workloads, trials of 1.7e7 / 3.4e7 / 6.7e7 / 1.3e8 photons chose
+  // 8 / 16 / 20-24 / 24 on the radar-like field (8 costs 13 % of the rate of 24) and 20-32 / 20 / 24 / 24 on the cloud field
   // (radiance runs cost several times more per photon: fewer trial photons, so that the ten trial launches stay well under a second)
   const unsigned long long want = c->tuneTrialPhotons / (unsigned long long)(1 + 2 * c->nDir);
   const unsigned long long total = ppb * (unsigned long long)nBatches;
   if (total < want) {
     // too few photons for a meaningful trial: a guess by domain size (few faces per leg on small grids, many on
     // large ones), and the trial is left for a later, larger call
-    c->eventThreshold = plan_launch(c, (size_t)p.slabStride).gridLds ? 16 : 32;
+    c->eventThreshold = plan_launch(c, (size_t)p.slabStride).gridLds ? 16 : 24;
     return 0;
   }
   const int nb = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)nBatches, want / std::max<unsigned long long>(1, ppb)));

@@ -79,6 +79,8 @@ def main():
                 print('   per photon: legs %.2f crossings %.2f collisions %.2f' % (c['legs'] / n, c['crossings'] / n, c['collisions'] / n))
                 print('   walk iters %.4g lanes/iter %.1f | event phases %.4g lanes/phase %.1f | launch phases %.4g surf phases %.4g | walk iters per event phase %.2f' % (c['walkIterations'], c['walkLanes']/max(1,c['walkIterations']), c['eventPhases'], c['eventLanes']/max(1,c['eventPhases']), c['launchPhases'], c['surfacePhases'], c['walkIterations']/max(1,c['eventPhases'])))
             res = integ.reportResults()
+            if thr == 0:
+                print("   (event threshold chosen by the trial launches: %d)" % integ.eventThreshold())
             print("case=%s n=%d bw=%d skip=%d bpc=%d priv=%d block=%d thr=%d lthr=%d sthr=%d brick=%d inflight=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
                 a.case, a.n, bw, skip, bpc, priv, block, thr, lthr, sthr, brick, inflight, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
                 res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"]), flush=True)
