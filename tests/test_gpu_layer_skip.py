@@ -7,6 +7,8 @@ oracle stop at every x and y face, which inside such a layer changes nothing but
 accumulated optical depth.  So: histories against the oracle and against the face-by-face kernel walk
 (layerSkip = 0) on the same Philox streams, the count of faces crossed, and the edge cases of the fold
 (many periodic wraps, reflecting surface under a clear run, irregular spacing)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,7 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 SEED = 4711
+FUZZ = int(os.environ.get("MCBRAT_FLIGHT_FUZZ", "12"))  # seeds of the random differential test (raise it for a soak run)
 
 
 @pytest.fixture(scope="module")
@@ -149,7 +152,7 @@ def test_irregular_columns_with_clear_runs(M):
     assert np.all(np.abs(means[1] - means[0]) < 2.5e-3), (means[1], means[0])
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(FUZZ))
 def test_random_domains_against_face_by_face_walk(M, seed):
     """Differential test on random small domains: random grid spacing (equal or stretched), random pattern of
     one-extinction layers (including none and all), vacuum layers, one or two components, random sun and surface.
@@ -185,8 +188,12 @@ def test_random_domains_against_face_by_face_walk(M, seed):
         means[skip] = np.array([res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"]])
         integ.finalize()
     same = _same(fates[1], fates[0])
-    assert same.mean() > 0.97, (case["name"], nx, ny, nz, same.mean())
-    assert same[fates[0]["nScatter"] <= 2].mean() > 0.995
+    # (long histories are chaotic: without roulette, under a bright surface, a photon scatters dozens of times and one
+    # rounding difference in the optical depth changes the rest of its history -- a soak run of 400 seeds found five media
+    # with 89-97 % overall, every one of them 100 % up to ten scatterings and with equal fluxes; scripts/soak_probe.py)
+    order = fates[0]["nScatter"]
+    assert same.mean() > (0.97 if order.mean() < 10 else 0.8), (case["name"], nx, ny, nz, same.mean(), order.mean())
+    assert same[order <= 10].mean() > 0.995
     assert np.all(np.abs(means[1] - means[0]) < 4e-3), (means[1], means[0])
     a = case["albedo"]
     assert abs(means[1][0] + means[1][2] + (1.0 - a) * means[1][1] - 1.0) < 4.0 / np.sqrt(n)
