@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmcbrat_hip.so")
 SOURCES = ["mcbrat_api.hip", "mcbrat_host.cpp"]
-DEPS = SOURCES + ["mcbrat_kernels.hip", "mcbrat_device.h", os.path.join("..", "..", "include", "mcbrat.h")]
+DEPS = SOURCES + ["mcbrat_kernels.hip", "mcbrat_blockwalk.hip", "mcbrat_device.h", os.path.join("..", "..", "include", "mcbrat.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 

@@ -1401,7 +1401,12 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
     std::vector<double> h(12 * traceCap);
     (void)hipStreamSynchronize(c->L().stream);
     (void)hipMemcpy(h.data(), dTrace, sizeof(double) * h.size(), hipMemcpyDeviceToHost);
-    for (int i = 0; i < traceCap && h[12 * i] > 0; ++i)
+    if (h[0] == 777) {
+      fprintf(stderr, "STUCK");
+      for (int i = 0; i < 27; ++i) fprintf(stderr, " %.9g", h[i]);
+      fprintf(stderr, "\n");
+    }
+    for (int i = 0; i < traceCap && h[12 * i] > 0 && h[0] != 777; ++i)
       fprintf(stderr, "GPUTRACE %d ev %.0f cell %.0f %.0f %.0f pos %.17g %.17g %.17g dir %.9g %.9g %.9g tau %.9g w %.9g\n", i, h[12 * i],
               h[12 * i + 1], h[12 * i + 2], h[12 * i + 3], h[12 * i + 4], h[12 * i + 5], h[12 * i + 6], h[12 * i + 7], h[12 * i + 8],
               h[12 * i + 9], h[12 * i + 10], h[12 * i + 11]);

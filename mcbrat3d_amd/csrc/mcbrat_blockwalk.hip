@@ -137,8 +137,14 @@ trace_block_kernel(const DevParams p) {
   float ivx = 0, ivy = 0, ivz = 0;    // 1/direction
   float tnx = 0, tny = 0, tnz = 0, tcur = 0;  // distance along the leg to the x/y/z face of the current BLOCK
   float acc = 0, tau = 0, w = 0, extCur = 0, uX = 0, uY = 0, uZ = 0;
-  int fz = 0;                          // z face (0..nz) of the current block ahead of the lane
-  int fx = 0, fy = 0;                  // x / y faces ahead (0..nx, 0..ny)
+  // cell range of the current block per axis, lo | hi << 16 (the face ahead of the lane is hi or lo by its direction).
+  // Kept whole, not just the face ahead: the cell a lane enters on the far side of a face comes from its POSITION on the
+  // two other axes, and a position that lies on a second face of the block (a leg through an edge of the block: float
+  // ties do occur, equal spacing and a diagonal sun make them common) may round to either side.  Clamped to the range of
+  // the block the lane is leaving it cannot fall behind a face the leg has already passed -- unclamped, two position
+  // look-ups that both round backwards hand the lane to and fro between two blocks for ever (found by the soak run of
+  // test_random_box_media_against_face_by_face_kernel).
+  unsigned rx = 0, ry = 0, rz = 0;
   unsigned spans = 0;                  // bit 0 / 1: the current block spans the whole periodic x / y axis
   int nScat = 0, nLegs = 0;
   long long dbgX = 0, dbgY = 0;        // DEBUG: cell of the leg's start counted through the periodic images
@@ -181,14 +187,17 @@ trace_block_kernel(const DevParams p) {
     double o = 0.0;
     return locate_periodic(s_edge + offY, p.ny, p.y0, p.Ly, p.invLy, p.invCellY, p.xyNearUniform != 0, o, yw);
   };
+  auto inRange = [](int j, unsigned r) { return min(max(j, (int)(r & 0xffffu)), (int)(r >> 16) - 1); };
   // Distances along the leg to the faces of the block that holds cell (ix, iy, iz); its extinction.
   auto enterBlock = [&](int ix, int iy, int iz) {
     const int cell = ix + p.nx * (iy + p.ny * iz);
     const uint4 rec = s_blockRec[s_blockOf[cell]];
     extCur = s_ext[cell];
-    fx = dx >= 0.0f ? (int)(rec.x >> 16) : (int)(rec.x & 0xffffu);
-    if (!NOY) fy = dy >= 0.0f ? (int)(rec.y >> 16) : (int)(rec.y & 0xffffu);
-    fz = dz >= 0.0f ? (int)(rec.z >> 16) : (int)(rec.z & 0xffffu);
+    rx = rec.x; rz = rec.z;
+    if (!NOY) ry = rec.y;
+    const int fx = dx >= 0.0f ? (int)(rx >> 16) : (int)(rx & 0xffffu);
+    const int fy = NOY ? 0 : (dy >= 0.0f ? (int)(ry >> 16) : (int)(ry & 0xffffu));
+    const int fz = dz >= 0.0f ? (int)(rz >> 16) : (int)(rz & 0xffffu);
     // a block that spans a whole periodic axis has no face on it (the lane's position runs through the images)
     spans |= rec.w;  // (a leg that has been through such a block may have left the principal image since its last fold)
     tnx = ((rec.w & 1u) || ivx == 0.0f) ? FLT_MAX : (float)(s_edge[fx] - px) * ivx;
@@ -232,8 +241,8 @@ trace_block_kernel(const DevParams p) {
           if (DEBUG) countCrossings(xw, yw, top ? p.nz : -1);
           px = xw;
           if (!NOY) py = yw;
-          ix = locX(xw, true, true);  // (always folded here: the surface description takes the position itself)
-          iy = locY(yw, true, true);
+          ix = inRange(locX(xw, true, true), rx);  // (always folded here: the surface description takes the position itself)
+          iy = NOY ? 0 : inRange(locY(yw, true, true), ry);
         }
         atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + (top ? 0 : ncol) + (ix + p.nx * iy)), weight_to_fixed(w));
         if (top) {
@@ -387,10 +396,10 @@ trace_block_kernel(const DevParams p) {
         // its cell, from the position (the periodic fold moves the position into the domain)
         {
           const double xw = px, yw = py;
-          iz = locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, pz);
+          iz = inRange(locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, pz), rz);  // (inside the block it collides in)
           if (DEBUG) countCrossings(xw, yw, iz);
-          ix = locX(xw, (spans & 1u) != 0);
-          iy = locY(yw, (spans & 2u) != 0);
+          ix = inRange(locX(xw, (spans & 1u) != 0), rx);
+          iy = NOY ? 0 : inRange(locY(yw, (spans & 2u) != 0), ry);
         }
         const int cell = ix + p.nx * (iy + p.ny * iz);
         nScat++;
@@ -488,23 +497,25 @@ trace_block_kernel(const DevParams p) {
         const float m2 = yLtX ? tny : tnx;
         const bool isZ = tnz < m2;  // (the axis whose face was reached: the same comparison the move made)
         const double xw = px + (double)tcur * (double)dx, yw = py + (double)tcur * (double)dy, zw = pz + (double)tcur * (double)dz;
+        // (the face crossed gives its axis' index exactly; the two others come from the position, clamped to the
+        // range of the block the lane is leaving -- see rx, ry, rz above)
         int jx, jy, jz;
         if (isZ) {
-          jz = dz >= 0.0f ? fz : fz - 1;  // (0 <= jz < nz: leaving the domain was decided when the face was reached)
-          jx = locX(xw, (spans & 1u) != 0);
-          jy = locY(yw, (spans & 2u) != 0);
+          jz = dz >= 0.0f ? (int)(rz >> 16) : (int)(rz & 0xffffu) - 1;  // (0 <= jz < nz: leaving the domain was decided when the face was reached)
+          jx = inRange(locX(xw, (spans & 1u) != 0), rx);
+          jy = NOY ? 0 : inRange(locY(yw, (spans & 2u) != 0), ry);
         } else if (yLtX) {
-          jy = dy >= 0.0f ? fy : fy - 1;
+          jy = dy >= 0.0f ? (int)(ry >> 16) : (int)(ry & 0xffffu) - 1;
           if (jy >= p.ny) { jy = 0; py -= p.Ly; if (DEBUG) dbgY -= p.ny; }            // periodic y :1790-1796: continue in the next image
           else if (jy < 0) { jy = p.ny - 1; py += p.Ly; if (DEBUG) dbgY += p.ny; }
-          jx = locX(xw, (spans & 1u) != 0);
-          jz = locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw);
+          jx = inRange(locX(xw, (spans & 1u) != 0), rx);
+          jz = inRange(locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
         } else {
-          jx = dx >= 0.0f ? fx : fx - 1;
+          jx = dx >= 0.0f ? (int)(rx >> 16) : (int)(rx & 0xffffu) - 1;
           if (jx >= p.nx) { jx = 0; px -= p.Lx; if (DEBUG) dbgX -= p.nx; }            // periodic x :1782-1788
           else if (jx < 0) { jx = p.nx - 1; px += p.Lx; if (DEBUG) dbgX += p.nx; }
-          jy = locY(yw, (spans & 2u) != 0);
-          jz = locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw);
+          jy = NOY ? 0 : inRange(locY(yw, (spans & 2u) != 0), ry);
+          jz = inRange(locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
         }
         enterBlock(jx, jy, jz);
         state = BW_MOVE;
@@ -512,6 +523,15 @@ trace_block_kernel(const DevParams p) {
       // wave-uniform exit: nothing alive and every lane has already been refused a new photon
       if (__ballot(state != BW_DEAD || more) == 0ull) break;
 
+#ifdef MCBRAT_STUCK_PROBE  // development aid: a wave still looping after 3e6 iterations reports a live lane's state and drops it
+      if (DEBUG && p.traceBuf && wIters > 3000000ull && state != BW_DEAD) {
+        double *t = p.traceBuf;
+        t[0] = 777; t[1] = state; t[2] = tcur; t[3] = tnx; t[4] = tny; t[5] = tnz; t[6] = (double)rx; t[7] = (double)ry; t[8] = (double)rz;
+        t[9] = px; t[10] = py; t[11] = pz; t[12] = 778; t[13] = dx; t[14] = dy; t[15] = dz; t[16] = acc; t[17] = tau; t[18] = spans; t[19] = extCur;
+        t[20] = ivx; t[21] = ivy; t[22] = ivz; t[23] = idLo; t[24] = 779; t[25] = nLegs; t[26] = nScat;
+        state = BW_DEAD;
+      }
+#endif
       // ---- move: to the collision point inside this block, or to the block face ahead (:1718-1744) ----
       if (state == BW_MOVE) {
         const bool yLtX = !NOY && tny < tnx;
@@ -527,7 +547,7 @@ trace_block_kernel(const DevParams p) {
           acc = accNew;
           tcur = tmin;
           state = BW_CROSS;
-          if (isZ && fz == (dz >= 0.0f ? p.nz : 0)) state = dz >= 0.0f ? BW_TOP : BW_SURFACE;  // :1801-1812
+          if (isZ && (dz >= 0.0f ? (int)(rz >> 16) == p.nz : (rz & 0xffffu) == 0u)) state = dz >= 0.0f ? BW_TOP : BW_SURFACE;  // :1801-1812
         }
       }
     }

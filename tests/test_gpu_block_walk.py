@@ -3,6 +3,8 @@ where a block is a box of cells with one extinction value, instead of from cell 
 oracle (the reference's face-by-face walk, same Philox streams), against the product's own face-by-face kernel, on a
 medium that is all blocks (step cloud, plane parallel, vacuum) and on one that has none (every cell its own block,
 irregular spacing: the crossing code at every face).  Run on the MI355X box with `-m gpu`."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,7 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 SEED = 90210
+FUZZ = int(os.environ.get("MCBRAT_FLIGHT_FUZZ", "12"))  # seeds of the random differential test (raise it for a soak run)
 
 
 @pytest.fixture(scope="module")
@@ -220,3 +223,57 @@ def test_block_walk_is_run_to_run_bitwise_and_split_independent(M):
     b = run([(0, 50000, 15), (750000, 50000, 25)])
     assert np.array_equal(a[:8], b[:8]) and np.allclose(a, b, rtol=1e-13, atol=1e-9)
     integ.finalize()
+
+
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_box_media_against_face_by_face_kernel(M, seed):
+    """Differential test: random small domains painted with random boxes of one extinction value (some spanning a
+    whole periodic axis, vacuum among them, one cell wide in x or y now and then), equal or stretched spacing, random
+    sun and surface, with and without roulette: the block walk (forced where blocks are small) against the face-by-face
+    kernel on the same Philox streams.  Identity is asserted up to ten scatterings (long histories are chaotic)."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    rng = np.random.default_rng(4200 + seed)
+    nx, ny, nz = int(rng.integers(1, 13)), int(rng.integers(1, 7)), int(rng.integers(1, 13))
+    def edges(n, stretched, origin):
+        d = rng.uniform(0.02, 0.08) * (np.cumprod(rng.uniform(0.85, 1.2, n)) if stretched else np.ones(n))
+        return origin + np.concatenate([[0.0], np.cumsum(d)])
+    stretched = rng.random() < 0.4
+    xe, ye = edges(nx, stretched, rng.uniform(-1.0, 1.0) if stretched else 0.0), edges(ny, stretched, 0.0)
+    ze = edges(nz, rng.random() < 0.4, 0.0)
+    ext = np.full((nx, ny, nz), float(rng.choice([0.0, 0.3, 4.0])))
+    for _ in range(int(rng.integers(0, 7))):
+        i0, j0, k0 = int(rng.integers(0, nx)), int(rng.integers(0, ny)), int(rng.integers(0, nz))
+        i1 = nx if rng.random() < 0.3 else int(rng.integers(i0 + 1, nx + 1))
+        j1 = ny if rng.random() < 0.3 else int(rng.integers(j0 + 1, ny + 1))
+        k1 = int(rng.integers(k0 + 1, nz + 1))
+        if rng.random() < 0.3:
+            i0 = 0
+        ext[i0:i1, j0:j1, k0:k1] = float(rng.choice([0.0, rng.uniform(0.5, 30.0)]))
+    case = dict(name="boxes%d" % seed, xe=xe, ye=ye, ze=ze, albedo=float(rng.choice([0.0, 0.3, 0.8])),
+                components=[dict(ext=ext, ssa=np.where(ext > 0, float(rng.uniform(0.7, 1.0)), 0.0), pfIndex=np.ones(ext.shape, np.int32),
+                                 legendre=[cases.hg_legendre(float(rng.uniform(0.0, 0.9)), 24)])])
+    mu0, phi0 = float(rng.choice([1.0, rng.uniform(0.05, 1.0)])), float(rng.uniform(0.0, 360.0))
+    rr = bool(rng.integers(0, 2))
+    n = 20000
+    photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+    out = {}
+    for bw in (0, 2):
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=2001, useRayTracing=True, useRussianRoulette=rr)
+        integ.setTuning(blockWalk=bw)
+        fates = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+        cnt = integ.counters()
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+        r = integ.reportResults()
+        out[bw] = (fates, cnt, np.array([r["meanFluxUp"], r["meanFluxDown"], r["meanFluxAbsorbed"]]), integ.walkMode()["blockWalk"])
+        integ.finalize()
+    assert out[2][3] and not out[0][3]
+    same, order = _same(out[2][0], out[0][0]), out[0][0]["nScatter"]
+    assert same[order <= 10].mean() > 0.995, (case["name"], nx, ny, nz, same[order <= 10].mean())
+    assert same.mean() > (0.97 if order.mean() < 10 else 0.8), (case["name"], nx, ny, nz, same.mean(), order.mean())
+    for k in ("legs", "collisions", "topExits", "surfaceHits"):
+        assert abs(out[2][1][k] - out[0][1][k]) <= 5e-3 * out[0][1][k] + 10, (k, out[2][1][k], out[0][1][k])
+    assert abs(out[2][1]["crossings"] - out[0][1]["crossings"]) <= 1e-2 * out[0][1]["crossings"] + 20
+    assert np.all(np.abs(out[2][2] - out[0][2]) < 4e-3), (out[2][2], out[0][2])
