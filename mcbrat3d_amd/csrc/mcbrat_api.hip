@@ -851,7 +851,7 @@ int mcbrat_set_optics(mcbrat_ctx *c, int32_t nc, const double *totalExt, const d
       const size_t i = (size_t)k * nvox + v;
       if (totalExt[v] > 0.0 && !(ssa[i] >= 0.0 && ssa[i] <= 1.0)) return fail(c, "validateOpticalComponent: singleScatteringAlbedo must be between 0 and 1.");
       cu[i] = (float)cumExt[i];
-      s[i] = (float)ssa[i];
+      s[i] = totalExt[v] > 0.0 ? (float)ssa[i] : 0.0f;  // (nothing collides without extinction; the block walk tells vacuum by this 0)
       int idx = pfIndex[i];
       if (totalExt[v] > 0.0 && (idx < 1 || idx > 65535)) return fail(c, "validateOpticalComponent: phaseFunctionIndex out of range.");
       if (idx < 1) idx = 1;
