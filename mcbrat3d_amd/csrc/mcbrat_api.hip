@@ -1406,8 +1406,8 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
       for (int i = 0; i < 27; ++i) fprintf(stderr, " %.9g", h[i]);
       fprintf(stderr, "\n");
     }
-    for (int i = 0; i < traceCap && h[12 * i] > 0 && h[0] != 777; ++i)
-      fprintf(stderr, "GPUTRACE %d ev %.0f cell %.0f %.0f %.0f pos %.17g %.17g %.17g dir %.9g %.9g %.9g tau %.9g w %.9g\n", i, h[12 * i],
+    for (int i = 0; i < traceCap && h[0] != 777; ++i)  // (indexed by scattering order: surface reflections leave gaps)
+      if (h[12 * i] > 0) fprintf(stderr, "GPUTRACE %d ev %.0f cell %.0f %.0f %.0f pos %.17g %.17g %.17g dir %.9g %.9g %.9g tau %.9g w %.9g\n", i, h[12 * i],
               h[12 * i + 1], h[12 * i + 2], h[12 * i + 3], h[12 * i + 4], h[12 * i + 5], h[12 * i + 6], h[12 * i + 7], h[12 * i + 8],
               h[12 * i + 9], h[12 * i + 10], h[12 * i + 11]);
     (void)hipFree(dTrace);

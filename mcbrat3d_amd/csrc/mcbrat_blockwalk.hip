@@ -387,7 +387,13 @@ trace_block_kernel(const DevParams p) {
       }
       // ---- scattering event, computeRT :703-821 ----
       if (state == BW_COLLIDE) {
-        {  // opticalProperties.f95:1729-1738: the point inside the block where tau is used up
+        // opticalProperties.f95:1729-1738: the point inside the block where tau is used up.  (Not for a leg whose direction
+        // is NaN: the reference's inverse phase-function tables can hold a NaN -- a negative discriminant in the closed-form
+        // inversion, inversePhaseFunctions.f95:148-166; one entry in 9001 for a 64-term HG series with g = 0.5 -- and a photon
+        // that draws it keeps a NaN direction from then on.  In the reference, the oracle and the face-by-face kernel such a
+        // photon goes on colliding in the CELL it is in until its weight is gone; here the cell comes from the position, so
+        // the position must stay where it is -- moved along a NaN it would never die: found by the soak run against the oracle.)
+        if (dz == dz) {
           const double s = (double)(tcur + div_fast(tau - acc, extCur));
           px = px + s * (double)dx;
           if (!NOY) py = py + s * (double)dy;

@@ -366,3 +366,75 @@ def test_regular_grid_path(M):
     rf = O.compute_rt(P, O.solar_source(0.8, 10.0), O.philox_rng(SEED, 0), n, want_fates=True)["fates"]
     same = (got["fate"] == rf["fate"]) & (got["ix"] == rf["ix"]) & (got["iy"] == rf["iy"]) & (got["nScatter"] == rf["nScatter"])
     assert same.mean() > 0.995
+
+
+FUZZ = int(__import__("os").environ.get("MCBRAT_FLIGHT_FUZZ", "12"))  # seeds of the random differential test (raise it for a soak run)
+
+
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_domains_against_the_oracle(M, seed):
+    """Differential test against the ORACLE (the restated reference walk, Philox mode) on random small domains: random
+    grid (equal or stretched spacing, non-zero origin), random extinction with vacuum cells, one or two components, random
+    sun, surface and roulette setting; every walk of the product in turn -- face by face, with the layer-skipping walk and
+    the clear-air flight, and the block walk where the grid lives in LDS.  Histories are compared up to ten scatterings
+    (longer ones are chaotic), event counters and fluxes over all of them."""
+    from oracle import oracle as O
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case, mu0, phi0, rr = random_oracle_case(seed)
+    nx, ny, nz = len(case["xe"]) - 1, len(case["ye"]) - 1, len(case["ze"]) - 1
+    n = 15000
+    P = cases.oracle_problem(case, nsteps=9001, use_russian_roulette=rr)
+    ref = O.compute_rt(P, O.solar_source(mu0, phi0), O.philox_rng(SEED, 0), n, want_fates=True)
+    rf, order = ref["fates"], ref["fates"]["nScatter"]
+    norm = O.normalize(P, n, ref)
+    mu, md, ma, _ = O.report_means(P, norm)
+    for walk, tuning in (("face by face", dict(privateTallies=0, layerSkip=0)), ("layers + flight", dict(privateTallies=0, layerSkip=3)),
+                         ("LDS face by face", dict(blockWalk=0)), ("block walk", dict(blockWalk=2))):
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=rr)
+        integ.setTuning(eventThreshold=16, **tuning)
+        photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+        got = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+        cnt = integ.counters()
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+        res = integ.reportResults()
+        integ.finalize()
+        same = (got["fate"] == rf["fate"]) & (got["ix"] == rf["ix"]) & (got["iy"] == rf["iy"]) & (got["iz"] == rf["iz"]) & \
+            (got["nScatter"] == rf["nScatter"]) & (np.abs(got["weight"] - rf["weight"]) <= 1e-6)
+        assert same[order <= 10].mean() > 0.985, (walk, case["name"], nx, ny, nz, same[order <= 10].mean())
+        # (totals over ALL histories: where long ones diverge -- no roulette under a bright surface -- the two runs are
+        # in part independent samples of a heavy-tailed count; 3 of 500 soak seeds differed by 2-3 %)
+        for k in ("legs", "collisions", "topExits", "surfaceHits"):
+            assert abs(cnt[k] - ref["counters"][k]) <= 5e-2 * ref["counters"][k] + 10, (walk, k, cnt[k], ref["counters"][k])
+        for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
+            assert abs(g - r) < 5e-3, (walk, g, r)
+
+
+def random_oracle_case(seed):
+    rng = np.random.default_rng(31000 + seed)
+    nx, ny, nz = 4 * int(rng.integers(1, 4)), 4 * int(rng.integers(1, 3)), int(rng.integers(2, 13))
+    def edges(n, stretched, origin):
+        d = rng.uniform(0.02, 0.06) * (np.cumprod(rng.uniform(0.85, 1.2, n)) if stretched else np.ones(n))
+        return origin + np.concatenate([[0.0], np.cumsum(d)])
+    st = rng.random() < 0.4
+    xe, ye, ze = edges(nx, st, rng.uniform(-1.0, 1.0) if st else 0.0), edges(ny, st, 0.0), edges(nz, rng.random() < 0.5, 0.0)
+    ext = np.zeros((nx, ny, nz))
+    for k in range(nz):
+        kind = rng.choice(["vacuum", "haze", "broken", "random"])
+        if kind == "haze":
+            ext[:, :, k] = rng.choice([0.05, 2.0])
+        elif kind == "broken":
+            ext[:, :, k] = np.where(rng.random((nx, ny)) < rng.uniform(0.1, 0.9), rng.uniform(2.0, 30.0, (nx, ny)), rng.choice([0.0, 0.1]))
+        elif kind == "random":
+            ext[:, :, k] = rng.uniform(0.0, 20.0, (nx, ny)) * (rng.random((nx, ny)) < 0.9)
+    comps = [dict(ext=ext, ssa=np.where(ext > 0, float(rng.uniform(0.6, 1.0)), 0.0), pfIndex=np.ones(ext.shape, np.int32),
+                  legendre=[cases.hg_legendre(float(rng.uniform(0.0, 0.9)), 24)])]
+    if rng.random() < 0.4:
+        comps.append(dict(ext=rng.uniform(0.0, 0.3, nz), ssa=np.ones(nz), pfIndex=np.ones(nz, np.int32),
+                          legendre=[np.array([0.0, 0.1], np.float32)]))
+    case = dict(name="oracle%d" % seed, xe=xe, ye=ye, ze=ze, albedo=float(rng.choice([0.0, 0.3, 0.8])), components=comps)
+    mu0, phi0 = float(rng.choice([1.0, rng.uniform(0.05, 1.0)])), float(rng.uniform(0.0, 360.0))
+    rr = bool(rng.integers(0, 2))
+    return case, mu0, phi0, rr
