@@ -313,3 +313,35 @@ def test_random_layerings_against_face_by_face_walk(M, seed):
     assert np.all(np.abs(b["means"] - a["means"]) < 4e-3), (b["means"], a["means"])
     if regular:  # (see test_random_fields_against_face_by_face_walk)
         assert abs(b["means"][0] + b["means"][2] + (1.0 - alb) * b["means"][1] - 1.0) < 4.0 / np.sqrt(n)
+
+
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_thermal_fields_against_face_by_face_walk(M, seed):
+    """Differential test with the emission source (photons start anywhere, in marked cells too, in every direction; emission
+    is tallied as negative absorption): random box clouds in a random background, flights against the face-by-face walk."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    rng = np.random.default_rng(15000 + seed)
+    nx, ny, nz = 4 * int(rng.integers(1, 4)), 4 * int(rng.integers(1, 3)), int(rng.integers(4, 14))
+    case = blobs(nx=nx, ny=ny, nz=nz, seed=300 + seed, background=float(rng.choice([0.0, 0.02, 0.3])), albedo=float(rng.choice([0.0, 0.2])),
+                 regular=bool(rng.random() < 0.5), ssa=float(rng.uniform(0.3, 0.9)), two=bool(rng.random() < 0.3))
+    case["temps"] = np.broadcast_to(rng.uniform(250.0, 290.0) - 2.0 * np.arange(nz), (nx, ny, nz)).copy()
+    case["sfc_temp"], case["lambda_um"] = float(rng.uniform(270.0, 310.0)), 10.0
+    n = 20000
+    out = {}
+    for skip in (0, 3):
+        dom = cases.product_domain(case)
+        w = M.new_Weights(nx, ny, nz)
+        M.emission_weighting(dom, w, case["sfc_temp"])
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=bool(seed % 2), LW_flag=1.0)
+        integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=skip)
+        photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 9)
+        fates = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+        r = integ.reportResults()
+        out[skip] = (fates, np.array([r["meanFluxUp"], r["meanFluxDown"], r["meanFluxAbsorbed"]]))
+        integ.finalize()
+    same, order = _same(out[3][0], out[0][0]), out[0][0]["nScatter"]
+    assert same[order <= 10].mean() > 0.99, (case["name"], nx, ny, nz, same[order <= 10].mean())
+    assert np.all(np.abs(out[3][1] - out[0][1]) < 4e-3 * np.maximum(np.abs(out[0][1]), 1.0)), (out[3][1], out[0][1])
