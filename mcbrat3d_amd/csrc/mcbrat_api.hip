@@ -1402,9 +1402,11 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
     (void)hipStreamSynchronize(c->L().stream);
     (void)hipMemcpy(h.data(), dTrace, sizeof(double) * h.size(), hipMemcpyDeviceToHost);
     if (h[0] == 777) {
-      fprintf(stderr, "STUCK");
-      for (int i = 0; i < 27; ++i) fprintf(stderr, " %.9g", h[i]);
-      fprintf(stderr, "\n");
+      for (int r = 0; r < 64 && h[20 * r] == 777; ++r) {  // (-DMCBRAT_STUCK_PROBE: state tcur tnx tny tnz rx ry rz px py pz dx dy dz acc tau ext spans id)
+        fprintf(stderr, "STUCK %d:", r);
+        for (int i = 1; i < 20; ++i) fprintf(stderr, " %.9g", h[20 * r + i]);
+        fprintf(stderr, "\n");
+      }
     }
     for (int i = 0; i < traceCap && h[0] != 777; ++i)  // (indexed by scattering order: surface reflections leave gaps)
       if (h[12 * i] > 0) fprintf(stderr, "GPUTRACE %d ev %.0f cell %.0f %.0f %.0f pos %.17g %.17g %.17g dir %.9g %.9g %.9g tau %.9g w %.9g\n", i, h[12 * i],

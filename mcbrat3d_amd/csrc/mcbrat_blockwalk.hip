@@ -199,7 +199,7 @@ trace_block_kernel(const DevParams p) {
     const int fy = NOY ? 0 : (dy >= 0.0f ? (int)(ry >> 16) : (int)(ry & 0xffffu));
     const int fz = dz >= 0.0f ? (int)(rz >> 16) : (int)(rz & 0xffffu);
     // a block that spans a whole periodic axis has no face on it (the lane's position runs through the images)
-    spans |= rec.w;  // (a leg that has been through such a block may have left the principal image since its last fold)
+    spans |= rec.w;  // (in such a block the lane may leave the principal image: folded when it leaves the block)
     tnx = ((rec.w & 1u) || ivx == 0.0f) ? FLT_MAX : (float)(s_edge[fx] - px) * ivx;
     tny = (NOY || (rec.w & 2u) || ivy == 0.0f) ? FLT_MAX : (float)(s_edge[offY + fy] - py) * ivy;
     tnz = ivz == 0.0f ? FLT_MAX : (float)(s_edge[offZ + fz] - pz) * ivz;
@@ -241,8 +241,26 @@ trace_block_kernel(const DevParams p) {
           if (DEBUG) countCrossings(xw, yw, top ? p.nz : -1);
           px = xw;
           if (!NOY) py = yw;
-          ix = inRange(locX(xw, true, true), rx);  // (always folded here: the surface description takes the position itself)
-          iy = NOY ? 0 : inRange(locY(yw, true, true), ry);
+          // (always folded here: the surface description takes the position itself.  A position on the domain boundary
+          // folds to either side of it by rounding: where the clamp then keeps a cell at the other end of the axis, the
+          // origin takes the image next to that cell -- cell and position must agree when the reflected leg starts.)
+          const int jx = locX(xw, true, true);
+          ix = inRange(jx, rx);
+          if (ix != jx) {
+            const double lo = s_edge[rx & 0xffffu], hi = s_edge[rx >> 16];
+            if (px < lo && lo - px > px + p.Lx - hi) px += p.Lx;
+            else if (px > hi && px - hi > lo - (px - p.Lx)) px -= p.Lx;
+          }
+          iy = 0;
+          if (!NOY) {
+            const int jy = locY(yw, true, true);
+            iy = inRange(jy, ry);
+            if (iy != jy) {
+              const double lo = s_edge[offY + (ry & 0xffffu)], hi = s_edge[offY + (ry >> 16)];
+              if (py < lo && lo - py > py + p.Ly - hi) py += p.Ly;
+              else if (py > hi && py - hi > lo - (py - p.Ly)) py -= p.Ly;
+            }
+          }
         }
         atomicAdd(reinterpret_cast<unsigned long long *>(s_slab + (top ? 0 : ncol) + (ix + p.nx * iy)), weight_to_fixed(w));
         if (top) {
@@ -540,19 +558,31 @@ trace_block_kernel(const DevParams p) {
           jy = NOY ? 0 : inRange(locY(yw, (spans & 2u) != 0), ry);
           jz = inRange(locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
         }
+        // (every axis the block left spans has just been folded -- it cannot be the axis crossed, a spanning block has no
+        // face there.  The bits must not outlive the fold: a lane that has just WRAPPED stands on the domain boundary, and
+        // a second fold by floor() may take the image on the far side of it while the clamp keeps the cell on this side;
+        // the next face then lies behind the lane, tcur steps back, and the lane goes round a corner of four blocks for
+        // ever -- the third hang the soak runs found, test_random_domains_against_the_oracle seed 763, a grazing sun.)
+        spans = 0;
         enterBlock(jx, jy, jz);
         state = BW_MOVE;
       }
       // wave-uniform exit: nothing alive and every lane has already been refused a new photon
       if (__ballot(state != BW_DEAD || more) == 0ull) break;
 
-#ifdef MCBRAT_STUCK_PROBE  // development aid: a wave still looping after 3e6 iterations reports a live lane's state and drops it
-      if (DEBUG && p.traceBuf && wIters > 3000000ull && state != BW_DEAD) {
-        double *t = p.traceBuf;
-        t[0] = 777; t[1] = state; t[2] = tcur; t[3] = tnx; t[4] = tny; t[5] = tnz; t[6] = (double)rx; t[7] = (double)ry; t[8] = (double)rz;
-        t[9] = px; t[10] = py; t[11] = pz; t[12] = 778; t[13] = dx; t[14] = dy; t[15] = dz; t[16] = acc; t[17] = tau; t[18] = spans; t[19] = extCur;
-        t[20] = ivx; t[21] = ivy; t[22] = ivz; t[23] = idLo; t[24] = 779; t[25] = nLegs; t[26] = nScat;
-        state = BW_DEAD;
+#ifdef MCBRAT_STUCK_PROBE  // development aid: a wave still looping after 3e6 iterations records 64 iterations of its first live lane, then drops it
+      if (DEBUG && p.traceBuf && wIters > 3000000ull) {
+        const unsigned long long live = __ballot(state != BW_DEAD);
+        if (live != 0ull && lane == __ffsll((long long)live) - 1) {
+          const unsigned long long r = wIters - 3000001ull;
+          if (r < 64ull) {
+            double *t = p.traceBuf + 20 * r;
+            t[0] = 777; t[1] = state; t[2] = tcur; t[3] = tnx; t[4] = tny; t[5] = tnz; t[6] = (double)rx; t[7] = (double)ry; t[8] = (double)rz;
+            t[9] = px; t[10] = py; t[11] = pz; t[12] = dx; t[13] = dy; t[14] = dz; t[15] = acc; t[16] = tau; t[17] = extCur; t[18] = spans; t[19] = idLo;
+          } else {
+            state = BW_DEAD;
+          }
+        }
       }
 #endif
       // ---- move: to the collision point inside this block, or to the block face ahead (:1718-1744) ----

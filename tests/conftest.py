@@ -11,3 +11,5 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than a few seconds on CPU")
+    # (pytest-timeout registers this itself where it is installed; declared here so that the marks are known without it)
+    config.addinivalue_line("markers", "timeout: per-test time limit (pytest-timeout): a kernel that never ends fails its test")

@@ -225,7 +225,13 @@ def test_block_walk_is_run_to_run_bitwise_and_split_independent(M):
     integ.finalize()
 
 
-@pytest.mark.parametrize("seed", range(FUZZ))
+# seeds the soak runs of this test found bugs with, kept whatever FUZZ is: 168 (a leg through an edge of a block: two position
+# look-ups that both rounded backwards handed the lane to and fro for ever), 122 (a collision booked in the vacuum cell next door)
+SOAK_FINDS = (122, 168)
+
+
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("seed", sorted(set(range(FUZZ)) | set(SOAK_FINDS)))
 def test_random_box_media_against_face_by_face_kernel(M, seed):
     """Differential test: random small domains painted with random boxes of one extinction value (some spanning a
     whole periodic axis, vacuum among them, one cell wide in x or y now and then), equal or stretched spacing, random

@@ -371,7 +371,14 @@ def test_regular_grid_path(M):
 FUZZ = int(__import__("os").environ.get("MCBRAT_FLIGHT_FUZZ", "12"))  # seeds of the random differential test (raise it for a soak run)
 
 
-@pytest.mark.parametrize("seed", range(FUZZ))
+# seeds the soak runs of this test found bugs with, kept whatever FUZZ is: 71 (a NaN drawn from the inverse table, DESIGN.md
+# section 8, moved the block walk's photon along it for ever), 763 (a grazing sun: a wrap and a block face at the same step,
+# the origin folded back across the domain boundary, the block walk went round a corner for ever)
+SOAK_FINDS = (71, 763)
+
+
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("seed", sorted(set(range(FUZZ)) | set(SOAK_FINDS)))
 def test_random_domains_against_the_oracle(M, seed):
     """Differential test against the ORACLE (the restated reference walk, Philox mode) on random small domains: random
     grid (equal or stretched spacing, non-zero origin), random extinction with vacuum cells, one or two components, random
