@@ -280,6 +280,8 @@ def test_random_box_media_against_face_by_face_kernel(M, seed):
     assert same[order <= 10].mean() > 0.995, (case["name"], nx, ny, nz, same[order <= 10].mean())
     assert same.mean() > (0.97 if order.mean() < 10 else 0.8), (case["name"], nx, ny, nz, same.mean(), order.mean())
     for k in ("legs", "collisions", "topExits", "surfaceHits"):
-        assert abs(out[2][1][k] - out[0][1][k]) <= 5e-3 * out[0][1][k] + 10, (k, out[2][1][k], out[0][1][k])
+        # (totals over ALL histories: where long ones diverge the two runs are in part independent samples of a heavy-tailed
+        # count -- 3 of 4000 soak seeds, bright surfaces without roulette, differed by 0.7-1.2 % in the surface hits)
+        assert abs(out[2][1][k] - out[0][1][k]) <= 2e-2 * out[0][1][k] + 10, (k, out[2][1][k], out[0][1][k])
     assert abs(out[2][1]["crossings"] - out[0][1]["crossings"]) <= 1e-2 * out[0][1]["crossings"] + 20
     assert np.all(np.abs(out[2][2] - out[0][2]) < 4e-3), (out[2][2], out[0][2])

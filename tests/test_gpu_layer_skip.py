@@ -195,8 +195,11 @@ def test_random_domains_against_face_by_face_walk(M, seed):
     assert same.mean() > (0.97 if order.mean() < 10 else 0.8), (case["name"], nx, ny, nz, same.mean(), order.mean())
     assert same[order <= 10].mean() > 0.995
     assert np.all(np.abs(means[1] - means[0]) < 4e-3), (means[1], means[0])
+    # (energy closes in the domain MEANS only where the columns have equal areas: the reference averages the column fluxes
+    # without area weights, reportResults :881-884 -- soak seed 1510, two stretched columns, is 3 % off in both walks)
     a = case["albedo"]
-    assert abs(means[1][0] + means[1][2] + (1.0 - a) * means[1][1] - 1.0) < 4.0 / np.sqrt(n)
+    if np.allclose(np.diff(xe), np.diff(xe)[0]) and np.allclose(np.diff(ye), np.diff(ye)[0]):
+        assert abs(means[1][0] + means[1][2] + (1.0 - a) * means[1][1] - 1.0) < 4.0 / np.sqrt(n)
 
 
 @pytest.mark.parametrize("rr", [False, True])
