@@ -1,0 +1,57 @@
+"""Scheduling must not show in the results: workgroup size, thresholds of the queues, batches in flight and workgroups per
+CU -- and, for the face-by-face walk, private or global tallies and dense or bricked grids -- only change WHEN a lane does
+its work.  On random small domains (tests/test_gpu_parity.py::random_oracle_case) a random tuning must reproduce the
+default run of the same walk bit for bit: every photon's fate and the moment array of a three-batch run.  Three walks:
+face by face, layer-skipping walk with the clear-air flight, block walk."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import SEED, random_oracle_case
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+@pytest.fixture(scope="module")
+def M():
+    import mcbrat3d_amd
+    return mcbrat3d_amd
+
+
+FUZZ = int(os.environ.get("MCBRAT_FLIGHT_FUZZ", "12"))  # seeds of the random differential test (raise it for a soak run)
+
+
+def _run(M, case, mu0, phi0, rr, walk, tuning, n=12000):
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=rr)
+    integ.setTuning(**walk, **tuning)
+    photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+    fates = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+    integ.resetMoments()
+    integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n // 3, 3)
+    mom = integ.moments().copy()
+    integ.finalize()
+    return fates, mom
+
+
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_tunings_give_the_same_histories(M, seed):
+    case, mu0, phi0, rr = random_oracle_case(seed)
+    rng = np.random.default_rng(77000 + seed)
+    sched = dict(eventThreshold=int(rng.choice([1, 4, 16, 40, 64])), blockSize=int(rng.choice([0, 256, 512])),
+                 launchThreshold=int(rng.choice([1, 8, 32])), surfaceThreshold=int(rng.choice([1, 12, 32])),
+                 blocksPerCU=int(rng.choice([0, 1, 3])), maxBatchesInFlight=int(rng.choice([0, 1, 2])))
+    layout = dict(privateTallies=int(rng.integers(0, 2)), brickLayout=int(rng.integers(0, 2)))
+    for name, walk, base_tuning, tuning in (
+            ("face by face", dict(layerSkip=0, blockWalk=0), dict(eventThreshold=16, privateTallies=0, brickLayout=0), dict(**sched, **layout)),
+            ("layers + flight", dict(layerSkip=3, blockWalk=0, privateTallies=0, brickLayout=0), dict(eventThreshold=16), sched),
+            ("block walk", dict(blockWalk=2), dict(eventThreshold=16), {k: v for k, v in sched.items() if k != "blockSize"})):
+        base = _run(M, case, mu0, phi0, rr, walk, base_tuning)
+        got = _run(M, case, mu0, phi0, rr, walk, tuning)
+        for f in base[0].dtype.names:
+            assert np.array_equal(got[0][f], base[0][f], equal_nan=True), (name, f, tuning)
+        assert np.array_equal(got[1], base[1], equal_nan=True), (name, tuning)
