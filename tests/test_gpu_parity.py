@@ -419,6 +419,53 @@ def test_random_domains_against_the_oracle(M, seed):
             assert abs(g - r) < 5e-3, (walk, g, r)
 
 
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_thermal_domains_against_the_oracle(M, seed):
+    """The same random domains as thermal sources (LW_flag > 0): random temperatures, surface temperature and wavelength.
+    The emission weighting (the running voxel CDF and the atmosphere's share of the power) must equal the oracle's bit
+    for bit; then every walk of the product against the oracle's photon loop launched from the same CDF: histories up to
+    ten scatterings, event totals, mean fluxes (emission tallied as negative absorption)."""
+    from oracle import oracle as O
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case, _, _, rr = random_oracle_case(seed)
+    rng = np.random.default_rng(52000 + seed)
+    nx, ny, nz = len(case["xe"]) - 1, len(case["ye"]) - 1, len(case["ze"]) - 1
+    case["temps"] = rng.uniform(230.0, 300.0, (nx, ny, nz))
+    case["sfc_temp"] = float(rng.uniform(250.0, 320.0))
+    case["lambda_um"] = float(rng.uniform(6.0, 14.0))
+    n = 15000
+    P = cases.oracle_problem(case, nsteps=9001, use_russian_roulette=rr, lw_flag=1.0)
+    vw, frac, _ = O.emission_weighting(P, case["temps"].transpose(2, 1, 0).reshape(-1), case["lambda_um"], case["sfc_temp"])
+    ref = O.compute_rt(P, O.EmissionSource(vw, frac), O.philox_rng(SEED, 0), n, want_fates=True)
+    rf, order = ref["fates"], ref["fates"]["nScatter"]
+    mu, md, ma, _ = O.report_means(P, O.normalize(P, n, ref))
+    scale = max(abs(mu), abs(md), abs(ma), 1e-6)
+    for walk, tuning in (("face by face", dict(privateTallies=0, layerSkip=0)), ("layers + flight", dict(privateTallies=0, layerSkip=3)),
+                         ("LDS face by face", dict(blockWalk=0)), ("block walk", dict(blockWalk=2))):
+        dom = cases.product_domain(case)
+        w = M.new_Weights(nx, ny, nz)
+        M.emission_weighting(dom, w, case["sfc_temp"])
+        assert np.array_equal(vw, w.voxelWeights) and frac == w.fracAtmsPower
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=rr, LW_flag=1.0)
+        integ.setTuning(eventThreshold=16, **tuning)
+        photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 9)
+        got = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+        cnt = integ.counters()
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+        res = integ.reportResults()
+        integ.finalize()
+        same = (got["fate"] == rf["fate"]) & (got["ix"] == rf["ix"]) & (got["iy"] == rf["iy"]) & (got["iz"] == rf["iz"]) & \
+            (got["nScatter"] == rf["nScatter"]) & (np.abs(got["weight"] - rf["weight"]) <= 1e-6)
+        assert same[order <= 10].mean() > 0.985, (walk, case["name"], nx, ny, nz, same[order <= 10].mean())
+        for k in ("legs", "collisions", "topExits", "surfaceHits"):
+            assert abs(cnt[k] - ref["counters"][k]) <= 5e-2 * ref["counters"][k] + 10, (walk, k, cnt[k], ref["counters"][k])
+        for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
+            assert abs(g - r) < 1e-2 * scale, (walk, g, r)
+
+
 def random_oracle_case(seed):
     rng = np.random.default_rng(31000 + seed)
     nx, ny, nz = 4 * int(rng.integers(1, 4)), 4 * int(rng.integers(1, 3)), int(rng.integers(2, 13))
