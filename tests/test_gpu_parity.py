@@ -466,6 +466,55 @@ def test_random_thermal_domains_against_the_oracle(M, seed):
             assert abs(g - r) < 1e-2 * scale, (walk, g, r)
 
 
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_rich_domains_against_the_oracle(M, seed):
+    """The random domains once more with what the plain ones leave out: phase-function tables of several entries with a
+    random entry per cell, a third component (no 16-byte collision record for it: the general look-up), a reflecting
+    surface of random patches on positions of its own.  Every walk of the product against the oracle, as above."""
+    from oracle import oracle as O
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case, mu0, phi0, rr = random_oracle_case(seed)
+    rng = np.random.default_rng(64000 + seed)
+    nx, ny, nz = len(case["xe"]) - 1, len(case["ye"]) - 1, len(case["ze"]) - 1
+    comps = case["components"]
+    if rng.random() < 0.6:  # several table entries for the first component
+        ne = int(rng.integers(2, 5))
+        comps[0]["legendre"] = [cases.hg_legendre(float(g), 24) for g in rng.uniform(0.0, 0.9, ne)]
+        comps[0]["pfIndex"] = rng.integers(1, ne + 1, (nx, ny, nz)).astype(np.int32)
+    if rng.random() < 0.6:  # one more 3-D component, sparse, absorbing, its own table
+        e3 = rng.uniform(0.0, 10.0, (nx, ny, nz)) * (rng.random((nx, ny, nz)) < 0.3)
+        comps.append(dict(ext=e3, ssa=np.where(e3 > 0, rng.uniform(0.3, 1.0, e3.shape), 0.0), pfIndex=rng.integers(1, 4, e3.shape).astype(np.int32),
+                          legendre=[cases.hg_legendre(float(g), 16) for g in (0.2, 0.6, 0.85)]))
+    if rng.random() < 0.5:
+        case = cases.patchy_surface(case, nxs=int(rng.integers(1, 6)), nys=int(rng.integers(1, 5)), seed=int(rng.integers(0, 10 ** 6)))
+    n = 15000
+    P = cases.oracle_problem(case, nsteps=9001, use_russian_roulette=rr)
+    ref = O.compute_rt(P, O.solar_source(mu0, phi0), O.philox_rng(SEED, 0), n, want_fates=True)
+    rf, order = ref["fates"], ref["fates"]["nScatter"]
+    mu, md, ma, _ = O.report_means(P, O.normalize(P, n, ref))
+    for walk, tuning in (("face by face", dict(privateTallies=0, layerSkip=0)), ("layers + flight", dict(privateTallies=0, layerSkip=3)),
+                         ("LDS face by face", dict(blockWalk=0)), ("block walk", dict(blockWalk=2))):
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=rr, surfaceBDRF=cases.product_surface(case))
+        integ.setTuning(eventThreshold=16, **tuning)
+        photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+        got = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+        cnt = integ.counters()
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+        res = integ.reportResults()
+        integ.finalize()
+        same = (got["fate"] == rf["fate"]) & (got["ix"] == rf["ix"]) & (got["iy"] == rf["iy"]) & (got["iz"] == rf["iz"]) & \
+            (got["nScatter"] == rf["nScatter"]) & (np.abs(got["weight"] - rf["weight"]) <= 1e-6)
+        assert same[order <= 10].mean() > 0.985, (walk, case["name"], nx, ny, nz, len(comps), same[order <= 10].mean())
+        for k in ("legs", "collisions", "topExits", "surfaceHits"):
+            assert abs(cnt[k] - ref["counters"][k]) <= 5e-2 * ref["counters"][k] + 10, (walk, k, cnt[k], ref["counters"][k])
+        for g, r in ((res["meanFluxUp"], mu), (res["meanFluxDown"], md), (res["meanFluxAbsorbed"], ma)):
+            assert abs(g - r) < 5e-3, (walk, g, r)
+
+
 def random_oracle_case(seed):
     rng = np.random.default_rng(31000 + seed)
     nx, ny, nz = 4 * int(rng.integers(1, 4)), 4 * int(rng.integers(1, 3)), int(rng.integers(2, 13))
