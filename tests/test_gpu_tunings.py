@@ -55,3 +55,56 @@ def test_random_tunings_give_the_same_histories(M, seed):
         for f in base[0].dtype.names:
             assert np.array_equal(got[0][f], base[0][f], equal_nan=True), (name, f, tuning)
         assert np.array_equal(got[1], base[1], equal_nan=True), (name, tuning)
+
+
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_call_sequences_async_equals_sync(M, seed):
+    """A random sequence of calls -- computeRadiativeTransfer with random batch sizes and batch counts (the buffers of the
+    context's streams grow in between), resetMoments, reads of the moments and of the last batch's results -- gives
+    bit for bit the same in asynchronous mode (calls overlap on the GPU) as in synchronous mode."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case, mu0, phi0, rr = random_oracle_case(seed)
+    rng = np.random.default_rng(88000 + seed)
+    ops = []
+    for _ in range(int(rng.integers(4, 14))):
+        r = rng.random()
+        if r < 0.65:
+            ops.append(("trace", int(rng.integers(1, 6000)), int(rng.integers(1, 6))))
+        elif r < 0.8:
+            ops.append(("reset",))
+        elif r < 0.9:
+            ops.append(("moments",))
+        else:
+            ops.append(("report",))
+    ops.append(("trace", 2000, 2))
+    out = {}
+    for mode in ("sync", "async"):
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=rr)
+        integ.setTuning(eventThreshold=16)
+        integ.setAsync(mode == "async")
+        photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+        r = new_RandomNumberSequence(SEED)
+        seen = []
+        integ.resetMoments()
+        for op in ops:
+            if op[0] == "trace":
+                assert integ.computeRadiativeTransfer(dom, r, photons, op[1], op[2]) == op[1] * op[2]
+            elif op[0] == "reset":
+                integ.resetMoments()
+            elif op[0] == "moments":
+                seen.append(integ.moments().copy())
+            elif integ.moments()[0] > 0 or any(o[0] == "trace" for o in ops[:ops.index(op)]):
+                res = integ.reportResults()
+                seen.append(np.concatenate([np.ravel(np.asarray(res[k], np.float64)) for k in sorted(res)]))
+        integ.synchronize()
+        seen.append(integ.moments().copy())
+        res = integ.reportResults()
+        seen.append(np.concatenate([np.ravel(np.asarray(res[k], np.float64)) for k in sorted(res)]))
+        integ.finalize()
+        out[mode] = seen
+    assert len(out["sync"]) == len(out["async"])
+    for a, b in zip(out["sync"], out["async"]):
+        assert np.array_equal(a, b, equal_nan=True), ops
