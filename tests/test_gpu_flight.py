@@ -345,3 +345,47 @@ def test_random_thermal_fields_against_face_by_face_walk(M, seed):
     same, order = _same(out[3][0], out[0][0]), out[0][0]["nScatter"]
     assert same[order <= 10].mean() > 0.99, (case["name"], nx, ny, nz, same[order <= 10].mean())
     assert np.all(np.abs(out[3][1] - out[0][1]) < 4e-3 * np.maximum(np.abs(out[0][1]), 1.0)), (out[3][1], out[0][1])
+
+
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_midsize_fields_default_plan_against_face_by_face_walk(M, seed):
+    """What a caller gets who sets nothing: random cloud fields of 24-48 columns a side and 12-32 layers (most too large
+    for LDS: grid in global memory, collision records, the walk specialised for the spacing found -- equal on every axis,
+    stretched layers, stretched everything), the library's own plan and event threshold (trial launches), against the
+    face-by-face kernel on a dense grid on the same Philox streams."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    rng = np.random.default_rng(9000 + seed)
+    nx, ny, nz = 4 * int(rng.integers(6, 13)), 4 * int(rng.integers(6, 13)), int(rng.integers(12, 33))
+    spacing = int(rng.integers(0, 3))
+    case = blobs(nx=nx, ny=ny, nz=nz, seed=500 + seed, background=float(rng.choice([0.0, 0.02, 0.1, 0.4])), albedo=float(rng.choice([0.0, 0.3])),
+                 regular=spacing != 2, stretch_z=spacing == 1, two=bool(rng.random() < 0.5), ssa=float(rng.uniform(0.8, 1.0)))
+    ext = case["components"][0]["ext"]
+    for _ in range(int(rng.integers(5, 30))):  # more clouds than blobs() paints: a broken field
+        i0, j0, k0 = int(rng.integers(0, nx)), int(rng.integers(0, ny)), int(rng.integers(1, nz - 4))
+        ii, jj = np.arange(i0, i0 + int(rng.integers(2, 12))) % nx, np.arange(j0, j0 + int(rng.integers(2, 12))) % ny
+        ext[np.ix_(ii, jj, np.arange(k0, min(k0 + int(rng.integers(1, 8)), nz - 1)))] = rng.uniform(2.0, 60.0)
+    case["components"][0]["ssa"] = np.where(ext > 0, case["components"][0]["ssa"].max(), 0.0)
+    mu0, phi0 = float(rng.choice([1.0, rng.uniform(0.05, 1.0)])), float(rng.uniform(0.0, 360.0))
+    rr = bool(rng.integers(0, 2))
+    n = 30000
+    out = []
+    for default in (False, True):
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=rr)
+        if not default:
+            integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=0, blockWalk=0, brickLayout=0)
+        photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+        fates = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n // 2, 2)
+        r = integ.reportResults()
+        out.append((fates, np.array([r["meanFluxUp"], r["meanFluxDown"], r["meanFluxAbsorbed"]]), integ.walkMode()))
+        integ.finalize()
+    (fa, ma, _), (fb, mb, mode) = out
+    same, order = _same(fb, fa), fa["nScatter"]
+    assert same[order <= 10].mean() > 0.99, (case["name"], nx, ny, nz, spacing, mode, same[order <= 10].mean())
+    assert np.all(np.abs(mb - ma) < 4e-3), (mode, mb, ma)
+    if case["regular"]:
+        assert abs(mb[0] + mb[2] + (1.0 - case["albedo"]) * mb[1] - 1.0) < 4.0 / np.sqrt(n)
