@@ -389,3 +389,51 @@ def test_random_midsize_fields_default_plan_against_face_by_face_walk(M, seed):
     assert np.all(np.abs(mb - ma) < 4e-3), (mode, mb, ma)
     if case["regular"]:
         assert abs(mb[0] + mb[2] + (1.0 - case["albedo"]) * mb[1] - 1.0) < 4.0 / np.sqrt(n)
+
+
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_midsize_fields_radiance_default_plan_against_face_by_face_rays(M, seed):
+    """The same for radiances by local estimation: random view directions (up, and down where the rays' roulette is off),
+    random roulette threshold, the library's own plan (rays skip clear layers, long rays finish from the ray buffer)
+    against photons and rays that stop at every face, one batch on the same Philox streams."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    rng = np.random.default_rng(9500 + seed)
+    nx, ny, nz = 4 * int(rng.integers(5, 10)), 4 * int(rng.integers(5, 10)), int(rng.integers(10, 25))
+    spacing = int(rng.integers(0, 3))
+    case = blobs(nx=nx, ny=ny, nz=nz, seed=900 + seed, background=float(rng.choice([0.0, 0.02, 0.2])), albedo=float(rng.choice([0.0, 0.3])),
+                 regular=spacing != 2, stretch_z=spacing == 1, two=bool(rng.random() < 0.5), ssa=float(rng.uniform(0.8, 1.0)))
+    ext = case["components"][0]["ext"]
+    for _ in range(int(rng.integers(4, 20))):
+        i0, j0, k0 = int(rng.integers(0, nx)), int(rng.integers(0, ny)), int(rng.integers(1, nz - 4))
+        ii, jj = np.arange(i0, i0 + int(rng.integers(2, 10))) % nx, np.arange(j0, j0 + int(rng.integers(2, 10))) % ny
+        ext[np.ix_(ii, jj, np.arange(k0, min(k0 + int(rng.integers(1, 6)), nz - 1)))] = rng.uniform(2.0, 40.0)
+    case["components"][0]["ssa"] = np.where(ext > 0, case["components"][0]["ssa"].max(), 0.0)
+    rri = bool(rng.integers(0, 2))
+    nd = int(rng.integers(1, 4))
+    mus = [float(rng.uniform(0.15, 1.0)) * (1.0 if rri or rng.random() < 0.6 else -1.0) for _ in range(nd)]
+    phis = [float(rng.uniform(0.0, 360.0)) for _ in range(nd)]
+    mu0, phi0 = float(rng.uniform(0.2, 1.0)), float(rng.uniform(0.0, 360.0))
+    zeta = float(rng.choice([0.1, 0.3]))
+    n = 20000
+    res = []
+    for default in (False, True):
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, minForwardTableSize=9001, intensityMus=mus, intensityPhis=phis, computeIntensity=True,
+                                useRussianRoulette=bool(seed % 2), useRussianRouletteForIntensity=rri, zetaMin=zeta)
+        if not default:
+            integ.setTuning(privateTallies=0, eventThreshold=24, layerSkip=0, blockWalk=0, brickLayout=0)
+        photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
+        res.append(integ.reportResults())
+        integ.finalize()
+    a, b = res[0], res[1]
+    assert np.all(np.isfinite(b["intensity"]))
+    assert np.allclose(b["meanIntensity"], a["meanIntensity"], rtol=1e-2, atol=1e-6), (mus, b["meanIntensity"], a["meanIntensity"])
+    for d in range(nd):
+        scale = float(np.mean(np.abs(a["intensity"][:, :, d]))) + 1e-12
+        assert np.mean(np.abs(b["intensity"][:, :, d] - a["intensity"][:, :, d])) < 0.05 * scale, (d, mus[d])
+    for k in ("meanFluxUp", "meanFluxDown", "meanFluxAbsorbed"):
+        assert abs(b[k] - a[k]) < 4e-3, (k, b[k], a[k])
