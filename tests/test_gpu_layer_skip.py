@@ -192,8 +192,9 @@ def test_random_domains_against_face_by_face_walk(M, seed):
     # rounding difference in the optical depth changes the rest of its history -- a soak run of 400 seeds found five media
     # with 89-97 % overall, every one of them 100 % up to ten scatterings and with equal fluxes; scripts/soak_probe.py)
     order = fates[0]["nScatter"]
-    assert same.mean() > (0.97 if order.mean() < 10 else 0.8), (case["name"], nx, ny, nz, same.mean(), order.mean())
-    assert same[order <= 10].mean() > 0.995
+    assert same[order <= 10].mean() > 0.995, (case["name"], nx, ny, nz, same[order <= 10].mean())
+    # (over ALL histories only a floor: 6 of 30000 soak seeds had 96 % at 9-10 scatterings on average and 76-78 % at 35-45)
+    assert same.mean() > (0.95 if order.mean() < 10 else 0.7), (case["name"], nx, ny, nz, same.mean(), order.mean())
     assert np.all(np.abs(means[1] - means[0]) < 4e-3), (means[1], means[0])
     # (energy closes in the domain MEANS only where the columns have equal areas: the reference averages the column fluxes
     # without area weights, reportResults :881-884 -- soak seed 1510, two stretched columns, is 3 % off in both walks)
