@@ -28,13 +28,13 @@ extern "C" {
 
 #define MCBRAT_MAX_COMPONENTS 8
 #define MCBRAT_MAX_DIRECTIONS 64 /* intensity directions per run */
-#define MCBRAT_ABI_VERSION 1
+#define MCBRAT_ABI_VERSION 2
 
 typedef struct mcbrat_ctx mcbrat_ctx;
 
 /* Per-photon record written by mcbrat_trace_fates (parity/debug only). */
 typedef struct {
-  int32_t fate;     /* 0 top exit, 1 absorbed by surface, 2 roulette kill, 3 dropped */
+  int32_t fate;     /* 0 top exit, 1 absorbed by surface, 2 roulette kill, 3 dropped by a loop bound (counters.badPhotons) */
   int32_t ix, iy, iz; /* 1-based cell of the final event */
   int32_t nScatter; /* scattering order at the end (:469, :643, :713) */
   int32_t nEvents;  /* legs traced */
@@ -48,6 +48,13 @@ typedef struct {
   /* wave-level loop statistics: iterations of the walk loop and lanes walking in them, event
    * phases and lanes served in them, phases that launched photons / reflected off the surface */
   int64_t walkIterations, walkLanes, eventPhases, eventLanes, launchPhases, surfacePhases;
+  /* Photons (and radiance rays) dropped since the context was created because they exceeded a loop bound of the
+   * kernels -- the analogue of computeRT's nBad (Integrators/monteCarloRadiativeTransfer.f95:562-563: a photon whose
+   * step is not positive is dropped and counted).  The reference's walk ends because it marches by cell index; the
+   * kernels here bound every loop instead (legs per photon, loop iterations of a wave without any lane starting a
+   * leg, length of a view ray), so that no input can keep a kernel from ending.  Always collected; 0 in every run
+   * the tests and bench.py make.  (ABI version 2.) */
+  int64_t badPhotons;
 } mcbrat_counters;
 
 int mcbrat_abi_version(void);
@@ -167,7 +174,7 @@ int mcbrat_get_moments(mcbrat_ctx *ctx, double *hostBuffer);
  * mcbrat_compute_radiative_transfer call, and its event counters (counters
  * are only collected when enabled; they cost a few percent). */
 int mcbrat_enable_counters(mcbrat_ctx *ctx, int32_t enable);
-int mcbrat_get_counters(mcbrat_ctx *ctx, mcbrat_counters *out);
+int mcbrat_get_counters(mcbrat_ctx *ctx, mcbrat_counters *out); /* synchronises; badPhotons is valid whether or not counters are enabled */
 float mcbrat_last_trace_ms(const mcbrat_ctx *ctx);
 /* Asynchronous mode.  A launch ends with its longest photon history, so every call carries a fixed
  * drain time; a caller that issues many calls -- the reference's driver calls
@@ -229,9 +236,11 @@ int mcbrat_set_surface_description(mcbrat_ctx *ctx, int32_t numX, int32_t numY, 
  * `segment x the same extinction` again.  0 restores the face-by-face walk; 2 uses the block walk even where blocks
  * hold fewer than four cells on average (a medium that differs from cell to cell: slower, meant for tests). */
 int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t blockWalk);
-/* The walk options in force: bit 0 layerSkip, bit 1 blockWalk, bit 2 the clear-air flight (asked for and possible on
- * the grid and optics loaded: brick columns exist, the background is thin enough or layerSkip = 3, no radiance
- * directions; a grid small enough to live in LDS does not use it either). */
+/* The walk a flux run of the loaded grid and optics uses, decided by the same plan as the launch itself: bit 0
+ * layerSkip, bit 1 the block walk (asked for AND applicable: grid, tallies and tables fit in LDS, blocks hold four
+ * cells or more on average, no radiance directions), bit 2 the clear-air flight (asked for and possible: brick columns
+ * exist, the background is thin enough or layerSkip = 3, no radiance directions, the grid is not held in LDS and the
+ * flight's tables fit beside the rest), bit 3 the blockWalk option as set.  Before grid and optics are loaded: the options. */
 int mcbrat_get_walk_mode(const mcbrat_ctx *ctx);
 
 /* The event threshold in use (after the first call of a domain: the one chosen by the trial launches). */

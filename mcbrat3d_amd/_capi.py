@@ -28,7 +28,7 @@ FATE_DTYPE = np.dtype([("fate", "<i4"), ("ix", "<i4"), ("iy", "<i4"), ("iz", "<i
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("legs", "crossings", "collisions", "absorbEvents", "topExits",
                                          "surfaceHits", "rouletteKills", "rouletteSurvivals", "walkIterations",
-                                         "walkLanes", "eventPhases", "eventLanes", "launchPhases", "surfacePhases")]
+                                         "walkLanes", "eventPhases", "eventLanes", "launchPhases", "surfacePhases", "badPhotons")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

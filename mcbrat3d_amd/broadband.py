@@ -94,15 +94,21 @@ class SpectralRun:
         for it in self.integrators:
             it.specifyParameters(**parameters)
         self.first = self.integrators[0]
-        self._bound = False
+        self._bound, self._bound_ptr = False, None
         self.streams, self.counts, self.cdf, self.totalFlux = None, None, None, 0.0
 
     def _bind(self):
-        if not self._bound:  # (after the parameters are final: intensity directions change the array's length)
-            ptr = self.first.momentsDevicePointer()
+        # The first integrator's moment array moves when its length changes (set_grid; specifyParameters with another
+        # number of intensity directions frees and re-allocates it): the others are bound again whenever the address
+        # they hold is no longer the one in use.  Contexts that share an array are only ordered in synchronous mode.
+        ptr = self.first.momentsDevicePointer()
+        if not self._bound or ptr != self._bound_ptr:
+            for it in self.integrators:
+                it.setAsync(False)
+                it._shares_moments = len(self.integrators) > 1
             for it in self.integrators[1:]:
                 it.bindMoments(ptr)
-            self._bound = True
+            self._bound, self._bound_ptr = True, ptr
 
     def bindMoments(self, device_ptr):
         """All wavelengths accumulate into a caller-owned device buffer (the tensor a multi-GPU run all-reduces)."""
@@ -144,6 +150,7 @@ class SpectralRun:
         data is touched.  Returns the counts; the moments (shared) are read from any integrator."""
         if self.streams is None:
             raise McbratError("SpectralRun: call prepare_thermal or prepare_solar first")
+        self._bind()
         total = int(numPhotonsPerBatch) * int(numBatches)
         self.counts = np.asarray(counts, np.int64) if counts is not None else \
             device_frequency_distribution(self.first, self.cdf, total, seed)

@@ -132,6 +132,15 @@ struct mcbrat_ctx {
   int blockWalk = 1;           // LDS-resident grids: blocks of cells with one extinction value are crossed in one step (MCBRAT_BLOCK_WALK=0 / mcbrat_set_walk_options)
   int layerSkip = 1;           // layers of one extinction value: cross z faces only; clear-air flight outside the brick columns' cloud
                                // ranges (MCBRAT_LAYER_SKIP / mcbrat_set_walk_options: 0 off, 1 both, 2 the layers only)
+  // loop bounds of the kernels (DevParams::bad ...) and the count of what they dropped
+  unsigned long long *dBad = nullptr;   // device: photons / rays dropped since the context was created
+  unsigned long long *hBad = nullptr;   // pinned host copy, refreshed after every launch
+  unsigned maxEvents = 1u << 24, maxEventsNaN = 4096u, watchdog = 1u << 20;  // MCBRAT_MAX_EVENTS, MCBRAT_WATCHDOG
+  int legacyTies = 0;                   // MCBRAT_TEST_LEGACY_TIES (tests only)
+  // mcbrat_frequency_distribution's device buffers, kept and grown with numLambda
+  double *dFreqCdf = nullptr;
+  unsigned long long *dFreqCounts = nullptr;
+  int freqCapacity = 0;
   bool countersOn = false;
   float lastTraceMs = 0.f;
   mcbrat_counters lastCounters{};
@@ -150,6 +159,17 @@ int fail(mcbrat_ctx *c, const std::string &msg) {
     if (e_ != hipSuccess) return fail(c, std::string(#call) + ": " + hipGetErrorString(e_));              \
   } while (0)
 
+// Every device allocation of the library.  -DMCBRAT_POISON (audit build): fresh memory is filled with 0xff, so that a
+// kernel that reads what nothing wrote reads NaNs / huge indices instead of whatever an earlier context left there.
+hipError_t dev_malloc(void **ptr, size_t bytes) {
+  hipError_t e = hipMalloc(ptr, bytes);
+#ifdef MCBRAT_POISON
+  if (e == hipSuccess) e = hipMemset(*ptr, 0xff, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+#endif
+  return e;
+}
+
 int init_lane(mcbrat_ctx *c, int i) {
   mcbrat_ctx::Lane &L = c->lane[i];
   if (L.stream) return 0;
@@ -157,7 +177,8 @@ int init_lane(mcbrat_ctx *c, int i) {
   HIP_OK(c, hipEventCreate(&L.ev0));
   HIP_OK(c, hipEventCreate(&L.ev1));
   HIP_OK(c, hipEventCreateWithFlags(&L.evDone, hipEventDisableTiming));
-  HIP_OK(c, hipMalloc((void **)&L.dCounter, sizeof(unsigned long long)));
+  HIP_OK(c, dev_malloc((void **)&L.dCounter, sizeof(unsigned long long)));
+  HIP_OK(c, hipMemset(L.dCounter, 0, sizeof(unsigned long long)));
   return 0;
 }
 
@@ -176,6 +197,7 @@ int sync_all(mcbrat_ctx *c) {
     c->timing.clear();
     c->lastTraceMs = total;
   }
+  if (c->hBad) c->lastCounters.badPhotons = (int64_t)*c->hBad;
   return 0;
 }
 
@@ -197,7 +219,7 @@ double spacing_d(double x) {
 template <typename T>
 int upload(mcbrat_ctx *c, T **dst, const T *src, size_t n) {
   if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
-  HIP_OK(c, hipMalloc((void **)dst, sizeof(T) * std::max<size_t>(n, 1)));
+  HIP_OK(c, dev_malloc((void **)dst, sizeof(T) * std::max<size_t>(n, 1)));
   if (n) HIP_OK(c, hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
   return 0;
 }
@@ -210,7 +232,7 @@ long long moments_len(const mcbrat_ctx *c) {
 int ensure_moments(mcbrat_ctx *c) {
   if (c->dMoments) return 0;
   const size_t n = 8 + 2 * (size_t)moments_len(c);
-  HIP_OK(c, hipMalloc((void **)&c->dMomentsOwned, sizeof(double) * n));
+  HIP_OK(c, dev_malloc((void **)&c->dMomentsOwned, sizeof(double) * n));
   HIP_OK(c, hipMemset(c->dMomentsOwned, 0, sizeof(double) * n));
   c->dMoments = c->dMomentsOwned;
   return 0;
@@ -464,6 +486,15 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.nBlocks = c->nBlocks; p.blockRec = reinterpret_cast<const uint4 *>(c->dBlockRec); p.blockOf = c->dBlockOf;
   p.crossThreshold = std::max(1, std::min(64, c->crossThreshold));
   p.jumpThreshold = std::max(1, std::min(64, c->jumpThreshold));
+  p.bad = c->dBad;
+  p.maxEvents = c->maxEvents; p.maxEventsNaN = c->maxEventsNaN; p.watchdog = c->watchdog;
+  p.legacyTies = c->legacyTies;
+  {
+    // no view ray is longer than the domain's height over the smallest |mu| of the views (and a hair for rounding)
+    float muMin = 1.0f;
+    for (int i = 0; i < c->nDir; ++i) muMin = std::min(muMin, std::fabs(c->dirData[(size_t)8 * i + 2]));
+    p.rayMaxLen = (float)((p.zMax - p.z0) / (double)std::max(muMin, FLT_MIN)) * 1.0001f + 1e-6f;
+  }
   p.counter = c->L().dCounter;
   p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
   p.launchThreshold = std::max(1, std::min(64, c->launchThreshold));
@@ -544,6 +575,7 @@ int launch_trace_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
     blocks = std::min(blocks, (p.total + BLOCK - 1) / BLOCK);
   }
   const unsigned grid = (unsigned)std::max<unsigned long long>(1, blocks);
+  p.ldsBytes = (unsigned)lds;
   hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC>), dim3(grid), dim3(BLOCK), lds, c->L().stream, p);
   HIP_OK(c, hipGetLastError());
   return 0;
@@ -632,6 +664,7 @@ int launch_block_s(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   p.unitsPerBatch = upb;
   p.nUnits = upb * (unsigned long long)nBatches;
   blocks = std::min(blocks, p.nUnits);
+  p.ldsBytes = (unsigned)lds;
   hipLaunchKernelGGL(kernel, dim3((unsigned)std::max<unsigned long long>(1, blocks)), dim3(BLOCK), lds, c->L().stream, p);
   HIP_OK(c, hipGetLastError());
   return 0;
@@ -753,16 +786,23 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (const char *e = getenv("MCBRAT_RAY_PASS_ITERS")) c->rayPassIters = std::max(1, atoi(e));
   if (const char *e = getenv("MCBRAT_RAY_PASS_AT")) c->rayPassAt = std::max(1, atoi(e));
   if (const char *e = getenv("MCBRAT_TUNE_PHOTONS")) c->tuneTrialPhotons = strtoull(e, nullptr, 10);
+  if (const char *e = getenv("MCBRAT_WATCHDOG")) c->watchdog = (unsigned)std::max(16ll, atoll(e));
+  if (const char *e = getenv("MCBRAT_MAX_EVENTS")) c->maxEvents = (unsigned)std::max(16ll, atoll(e));
+  if (const char *e = getenv("MCBRAT_TEST_LEGACY_TIES")) c->legacyTies = atoi(e);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
     c->numCUs = prop.multiProcessorCount;
     if (prop.maxSharedMemoryPerMultiProcessor > 0) c->ldsPerCU = prop.maxSharedMemoryPerMultiProcessor;
   }
   if (init_lane(c, 0) || hipEventCreateWithFlags(&c->evExternal, hipEventDisableTiming) != hipSuccess ||
-      hipMalloc((void **)&c->dEventCounters, 32 * sizeof(unsigned long long)) != hipSuccess) {
-    delete c;
+      dev_malloc((void **)&c->dEventCounters, 32 * sizeof(unsigned long long)) != hipSuccess ||
+      dev_malloc((void **)&c->dBad, sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->dBad, 0, sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc((void **)&c->hBad, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+    mcbrat_destroy(c);
     return nullptr;
   }
+  *c->hBad = 0ull;
   return c;
 }
 
@@ -772,7 +812,9 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   (void)sync_all(c);
   void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF,
                   c->dEventCounters, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
-                  c->dBlockRec, c->dBlockOf, c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dExtWalk, c->dBgVal, c->dFlyRange, c->dSurfX, c->dSurfY, c->dSurfRefl};
+                  c->dBlockRec, c->dBlockOf, c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dExtWalk, c->dBgVal, c->dFlyRange, c->dSurfX, c->dSurfY, c->dSurfRefl,
+                  c->dBad, c->dFreqCdf, c->dFreqCounts, c->dDirData, c->dFwd, c->dFwdOrig};
+  if (c->hBad) (void)hipHostFree(c->hBad);
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (mcbrat_ctx::Lane &L : c->lane) {
     void *lb[] = {L.dCounter, L.dSlabs, L.dColVals, L.dScalVals};
@@ -999,6 +1041,8 @@ int mcbrat_enable_counters(mcbrat_ctx *c, int32_t enable) {
 }
 int mcbrat_get_counters(mcbrat_ctx *c, mcbrat_counters *out) {
   if (!c || !out) return 1;
+  (void)hipSetDevice(c->device);
+  if (sync_all(c)) return 1;  // (asynchronous mode: badPhotons is read when the enqueued work has finished)
   *out = c->lastCounters;
   return 0;
 }
@@ -1187,10 +1231,17 @@ int mcbrat_frequency_distribution(mcbrat_ctx *c, uint64_t seed, uint64_t firstDr
   (void)hipSetDevice(c->device);
   if (init_lane(c, 0)) return 1;
   hipStream_t st = c->lane[0].stream;
-  double *dCdf = nullptr;
-  unsigned long long *dCounts = nullptr;
-  HIP_OK(c, hipMalloc((void **)&dCdf, sizeof(double) * numLambda));
-  HIP_OK(c, hipMalloc((void **)&dCounts, sizeof(unsigned long long) * numLambda));
+  if (c->freqCapacity < numLambda) {  // the context's own buffers, grown when a longer CDF arrives (freed with the context)
+    HIP_OK(c, hipStreamSynchronize(st));
+    if (c->dFreqCdf) { (void)hipFree(c->dFreqCdf); c->dFreqCdf = nullptr; }
+    if (c->dFreqCounts) { (void)hipFree(c->dFreqCounts); c->dFreqCounts = nullptr; }
+    c->freqCapacity = 0;
+    HIP_OK(c, dev_malloc((void **)&c->dFreqCdf, sizeof(double) * numLambda));
+    HIP_OK(c, dev_malloc((void **)&c->dFreqCounts, sizeof(unsigned long long) * numLambda));
+    c->freqCapacity = numLambda;
+  }
+  double *dCdf = c->dFreqCdf;
+  unsigned long long *dCounts = c->dFreqCounts;
   HIP_OK(c, hipMemcpyAsync(dCdf, cdf, sizeof(double) * numLambda, hipMemcpyHostToDevice, st));
   HIP_OK(c, hipMemsetAsync(dCounts, 0, sizeof(unsigned long long) * numLambda, st));
   if (totalPhotons > 0) {
@@ -1205,12 +1256,20 @@ int mcbrat_frequency_distribution(mcbrat_ctx *c, uint64_t seed, uint64_t firstDr
   HIP_OK(c, hipMemcpyAsync(h.data(), dCounts, sizeof(unsigned long long) * numLambda, hipMemcpyDeviceToHost, st));
   HIP_OK(c, hipStreamSynchronize(st));
   for (int i = 0; i < numLambda; ++i) distribution[i] = (int64_t)h[i];
-  (void)hipFree(dCdf);
-  (void)hipFree(dCounts);
   return 0;
 }
 
-int mcbrat_get_walk_mode(const mcbrat_ctx *c) { return c ? ((c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0) | ((flight_wanted(c) && c->nDir == 0 && !use_bricks(c)) ? 4 : 0)) : 0; }
+int mcbrat_get_walk_mode(const mcbrat_ctx *c) {
+  if (!c) return 0;
+  int m = (c->layerSkip ? 1 : 0) | (c->blockWalk ? 2 : 0);
+  if (c->haveGrid && c->haveOptics) {  // what a flux launch of the loaded domain would do (the plan decides, as launch_trace does)
+    const size_t ncol = (size_t)c->nx * c->ny;
+    LaunchPlan L = plan_launch(c, 2 * ncol + ncol * c->nz);
+    if (L.priv && L.brick) { L.priv = false; L.gridLds = false; }
+    m = (c->layerSkip ? 1 : 0) | (block_walk_applies(c, L) ? 2 : 0) | (L.fly ? 4 : 0) | (c->blockWalk ? 8 : 0);
+  }
+  return m;
+}
 
 int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int64_t ppb, int32_t nBatches,
                                       int64_t *numPhotonsProcessed) {
@@ -1248,23 +1307,23 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     if (L.slabCapacity < needSlab) {
       if (L.dSlabs) (void)hipFree(L.dSlabs);
       L.dSlabs = nullptr; L.slabCapacity = 0;
-      HIP_OK(c, hipMalloc((void **)&L.dSlabs, sizeof(long long) * needSlab));
+      HIP_OK(c, dev_malloc((void **)&L.dSlabs, sizeof(long long) * needSlab));
       L.slabCapacity = needSlab;
     }
     if (L.colCapacity < needCol) {
       if (L.dColVals) (void)hipFree(L.dColVals);
       L.dColVals = nullptr; L.colCapacity = 0;
-      HIP_OK(c, hipMalloc((void **)&L.dColVals, sizeof(float) * needCol));
+      HIP_OK(c, dev_malloc((void **)&L.dColVals, sizeof(float) * needCol));
       L.colCapacity = needCol;
     }
     if (L.scalCapacity < needScal) {
       if (L.dScalVals) (void)hipFree(L.dScalVals);
       L.dScalVals = nullptr; L.scalCapacity = 0;
-      HIP_OK(c, hipMalloc((void **)&L.dScalVals, sizeof(float) * needScal));
+      HIP_OK(c, dev_malloc((void **)&L.dScalVals, sizeof(float) * needScal));
       L.scalCapacity = needScal;
     }
   }
-  if (!c->dLast) HIP_OK(c, hipMalloc((void **)&c->dLast, sizeof(float) * (size_t)moments_len(c)));
+  if (!c->dLast) HIP_OK(c, dev_malloc((void **)&c->dLast, sizeof(float) * (size_t)moments_len(c)));
 
   DevParams p;
   fill_params(c, p);
@@ -1313,6 +1372,7 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     hipLaunchKernelGGL(finish_reduce, dim3(3 + c->nz, nb), dim3(256), 0, c->L().stream, f);
     hipLaunchKernelGGL(finish_scalars, dim3((unsigned)((3 + c->nz + 255) / 256)), dim3(256), 0, c->L().stream, f);
     HIP_OK(c, hipGetLastError());
+    HIP_OK(c, hipMemcpyAsync(c->hBad, c->dBad, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->L().stream));
     HIP_OK(c, hipEventRecord(c->L().evDone, c->L().stream));
     c->lastDone = c->L().evDone;
     if (async) continue;
@@ -1321,7 +1381,7 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     HIP_OK(c, hipEventElapsedTime(&ms, c->L().ev0, c->L().ev1));
     traceMs += ms;
   }
-  if (!async) c->lastTraceMs = traceMs;
+  if (!async) { c->lastTraceMs = traceMs; c->lastCounters.badPhotons = (int64_t)*c->hBad; }
   if (c->countersOn) {
     unsigned long long h[16];
     HIP_OK(c, hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost));
@@ -1338,7 +1398,8 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
 #endif
     c->lastCounters = mcbrat_counters{(int64_t)h[0], (int64_t)h[1], (int64_t)h[2], (int64_t)h[3],
                                       (int64_t)h[4], (int64_t)h[5], (int64_t)h[6], (int64_t)h[7],
-                                      (int64_t)h[8], (int64_t)h[9], (int64_t)h[10], (int64_t)h[11], (int64_t)h[12], (int64_t)h[13]};
+                                      (int64_t)h[8], (int64_t)h[9], (int64_t)h[10], (int64_t)h[11], (int64_t)h[12], (int64_t)h[13],
+                                      (int64_t)*c->hBad};
   }
   c->haveLast = true;
   if (numPhotonsProcessed) *numPhotonsProcessed = ppb * (int64_t)nBatches;
@@ -1377,8 +1438,8 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
   const size_t slabStride = 2 * ncol + nvox;
   long long *scratch = nullptr;
   mcbrat_fate *dF = nullptr;
-  HIP_OK(c, hipMalloc((void **)&scratch, sizeof(long long) * slabStride));
-  HIP_OK(c, hipMalloc((void **)&dF, sizeof(mcbrat_fate) * (size_t)n));
+  HIP_OK(c, dev_malloc((void **)&scratch, sizeof(long long) * slabStride));
+  HIP_OK(c, dev_malloc((void **)&dF, sizeof(mcbrat_fate) * (size_t)n));
   HIP_OK(c, hipMemsetAsync(scratch, 0, sizeof(long long) * slabStride, c->L().stream));
   HIP_OK(c, hipMemsetAsync(dF, 0xff, sizeof(mcbrat_fate) * (size_t)n, c->L().stream));
   HIP_OK(c, hipMemsetAsync(c->L().dCounter, 0, sizeof(unsigned long long), c->L().stream));
@@ -1392,7 +1453,7 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
   double *dTrace = nullptr;
   const int traceCap = 4096;
   if (const char *tp = getenv("MCBRAT_TRACE_PHOTON")) {  // development aid: per-collision records of one photon
-    HIP_OK(c, hipMalloc((void **)&dTrace, sizeof(double) * 12 * traceCap));
+    HIP_OK(c, dev_malloc((void **)&dTrace, sizeof(double) * 12 * traceCap));
     HIP_OK(c, hipMemsetAsync(dTrace, 0, sizeof(double) * 12 * traceCap, c->L().stream));
     p.traceBuf = dTrace; p.traceIndex = strtoull(tp, nullptr, 10); p.traceCap = traceCap;
   }
@@ -1419,10 +1480,12 @@ int mcbrat_trace_fates(mcbrat_ctx *c, uint64_t seed, uint64_t firstPhotonId, int
     if (e == hipSuccess) e = hipMemcpy(fates, dF, sizeof(mcbrat_fate) * (size_t)n, hipMemcpyDeviceToHost);
     unsigned long long h[16];
     if (e == hipSuccess) e = hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(c->hBad, c->dBad, sizeof(unsigned long long), hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(c, std::string("trace_fates: ") + hipGetErrorString(e));
     else c->lastCounters = mcbrat_counters{(int64_t)h[0], (int64_t)h[1], (int64_t)h[2], (int64_t)h[3],
                                            (int64_t)h[4], (int64_t)h[5], (int64_t)h[6], (int64_t)h[7],
-                                           (int64_t)h[8], (int64_t)h[9], (int64_t)h[10], (int64_t)h[11], (int64_t)h[12], (int64_t)h[13]};
+                                           (int64_t)h[8], (int64_t)h[9], (int64_t)h[10], (int64_t)h[11], (int64_t)h[12], (int64_t)h[13],
+                                           (int64_t)*c->hBad};
   }
   (void)hipFree(scratch);
   (void)hipFree(dF);

@@ -81,6 +81,10 @@ trace_block_kernel(const DevParams p) {
   const bool zRegular = SIMPLE != 0 ? true : p.zRegular != 0;
   const int nc = SIMPLE != 0 ? 1 : p.nc;
   extern __shared__ __align__(16) unsigned char smem_raw[];
+#ifdef MCBRAT_POISON  // audit build: whatever the kernel reads from LDS before it wrote it reads 0xff..
+  for (unsigned i = threadIdx.x; i < p.ldsBytes / 4u; i += BLOCK) reinterpret_cast<unsigned *>(smem_raw)[i] = 0xffffffffu;
+  __syncthreads();
+#endif
   // LDS map: [edges x|y|z (double)] [private tally slab (i64)] [unit cursor] [block records (uint4)] [extinction]
   //          [ssa] [cum] [phase index (u16)] [block of each cell (u16)] [tables (float), TBL_LDS]
   double *s_edge = reinterpret_cast<double *>(smem_raw);
@@ -188,6 +192,10 @@ trace_block_kernel(const DevParams p) {
     return locate_periodic(s_edge + offY, p.ny, p.y0, p.Ly, p.invLy, p.invCellY, p.xyNearUniform != 0, o, yw);
   };
   auto inRange = [](int j, unsigned r) { return min(max(j, (int)(r & 0xffffu)), (int)(r >> 16) - 1); };
+  // TEST ONLY (DevParams::legacyTies): the tie handling from before the three fixes the soak runs led to, to show that the
+  // bounds below end the kernel without them (tests/test_gpu_edge_cases.py).  Wave-uniform, read in the rare phases only.
+  const bool legacyNoClamp = (p.legacyTies & 1) != 0, legacyMoveNaN = (p.legacyTies & 2) != 0, legacyKeepSpans = (p.legacyTies & 4) != 0;
+  auto inRangeX = [&](int j, unsigned r) { return legacyNoClamp ? j : inRange(j, r); };  // clamp of a block crossing
   // Distances along the leg to the faces of the block that holds cell (ix, iy, iz); its extinction.
   auto enterBlock = [&](int ix, int iy, int iz) {
     const int cell = ix + p.nx * (iy + p.ny * iz);
@@ -205,6 +213,14 @@ trace_block_kernel(const DevParams p) {
     tnz = ivz == 0.0f ? FLT_MAX : (float)(s_edge[offZ + fz] - pz) * ivz;
   };
 
+  // Watchdog (wave-uniform, scalar; see trace_kernel): loop iterations in which no lane of the wave started a leg, took a
+  // new photon or was refused one.  When it fires every lane that is not dead is dropped and counted (DevParams::bad).
+  unsigned sinceProgress = 0;
+#define MCBRAT_BW_DROP() do { \
+    if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{3, 0, 0, 0, nScat, nLegs, w}; \
+    state = BW_DEAD; \
+    atomicAdd(p.bad, 1ull); \
+  } while (0)
   for (unsigned long long unit = blockIdx.x;; unit += gridDim.x) {
     if (unit >= p.nUnits) break;  // workgroup-uniform
     uint32_t batch;
@@ -411,7 +427,7 @@ trace_block_kernel(const DevParams p) {
         // that draws it keeps a NaN direction from then on.  In the reference, the oracle and the face-by-face kernel such a
         // photon goes on colliding in the CELL it is in until its weight is gone; here the cell comes from the position, so
         // the position must stay where it is -- moved along a NaN it would never die: found by the soak run against the oracle.)
-        if (dz == dz) {
+        if (dz == dz || legacyMoveNaN) {
           const double s = (double)(tcur + div_fast(tau - acc, extCur));
           px = px + s * (double)dx;
           if (!NOY) py = py + s * (double)dy;
@@ -506,6 +522,14 @@ trace_block_kernel(const DevParams p) {
         }
       }
       // ---- start the next leg: tau, 1/direction, the block the leg starts in ----
+      sinceProgress = (__ballot(needLeg) != 0ull || want != 0ull) ? 0u : sinceProgress + 1u;
+      if (sinceProgress > p.watchdog) {  // (wave-uniform; never in a run whose every lane makes progress)
+        if (state != BW_DEAD) MCBRAT_BW_DROP();
+        sinceProgress = 0u;
+      }
+      // (a photon is allowed maxEvents legs; one with a NaN direction -- see the collision above -- maxEventsNaN: where
+      // omega0 = 1 its weight never falls and neither the reference nor the roulette would ever end it)
+      if (needLeg && event >= (dz == dz ? p.maxEvents : p.maxEventsNaN)) { needLeg = false; MCBRAT_BW_DROP(); }
       if (needLeg) {
         event++;
         nLegs++;
@@ -543,27 +567,27 @@ trace_block_kernel(const DevParams p) {
         int jx, jy, jz;
         if (isZ) {
           jz = dz >= 0.0f ? (int)(rz >> 16) : (int)(rz & 0xffffu) - 1;  // (0 <= jz < nz: leaving the domain was decided when the face was reached)
-          jx = inRange(locX(xw, (spans & 1u) != 0), rx);
-          jy = NOY ? 0 : inRange(locY(yw, (spans & 2u) != 0), ry);
+          jx = inRangeX(locX(xw, (spans & 1u) != 0), rx);
+          jy = NOY ? 0 : inRangeX(locY(yw, (spans & 2u) != 0), ry);
         } else if (yLtX) {
           jy = dy >= 0.0f ? (int)(ry >> 16) : (int)(ry & 0xffffu) - 1;
           if (jy >= p.ny) { jy = 0; py -= p.Ly; if (DEBUG) dbgY -= p.ny; }            // periodic y :1790-1796: continue in the next image
           else if (jy < 0) { jy = p.ny - 1; py += p.Ly; if (DEBUG) dbgY += p.ny; }
-          jx = inRange(locX(xw, (spans & 1u) != 0), rx);
-          jz = inRange(locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
+          jx = inRangeX(locX(xw, (spans & 1u) != 0), rx);
+          jz = inRangeX(locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
         } else {
           jx = dx >= 0.0f ? (int)(rx >> 16) : (int)(rx & 0xffffu) - 1;
           if (jx >= p.nx) { jx = 0; px -= p.Lx; if (DEBUG) dbgX -= p.nx; }            // periodic x :1782-1788
           else if (jx < 0) { jx = p.nx - 1; px += p.Lx; if (DEBUG) dbgX += p.nx; }
-          jy = NOY ? 0 : inRange(locY(yw, (spans & 2u) != 0), ry);
-          jz = inRange(locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
+          jy = NOY ? 0 : inRangeX(locY(yw, (spans & 2u) != 0), ry);
+          jz = inRangeX(locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
         }
         // (every axis the block left spans has just been folded -- it cannot be the axis crossed, a spanning block has no
         // face there.  The bits must not outlive the fold: a lane that has just WRAPPED stands on the domain boundary, and
         // a second fold by floor() may take the image on the far side of it while the clamp keeps the cell on this side;
         // the next face then lies behind the lane, tcur steps back, and the lane goes round a corner of four blocks for
         // ever -- the third hang the soak runs found, test_random_domains_against_the_oracle seed 763, a grazing sun.)
-        spans = 0;
+        if (!legacyKeepSpans) spans = 0;
         enterBlock(jx, jy, jz);
         state = BW_MOVE;
       }
@@ -595,7 +619,7 @@ trace_block_kernel(const DevParams p) {
         if (accNew > tau) {
           state = BW_COLLIDE;  // :1729-1738: the stop point is resolved at the head of the next iteration
         } else if (!(tmin < FLT_MAX)) {
-          state = BW_DEAD;     // no face ahead and nothing to collide with (a horizontal leg through vacuum): the reference walks for ever
+          MCBRAT_BW_DROP();    // no face ahead and nothing to collide with (a horizontal leg through vacuum): the reference walks for ever
         } else {
           acc = accNew;
           tcur = tmin;

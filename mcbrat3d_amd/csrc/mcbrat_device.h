@@ -114,6 +114,19 @@ struct DevParams {
   int launchThreshold;            // idle lanes queued before new photons are launched
   int surfaceThreshold;           // lanes queued before exits (top / surface) are served
   int jumpThreshold;              // lanes queued before transitions of the layer-skipping walk are served
+  // Termination guarantees.  The reference's walk marches by cell INDEX and drops a photon whose step
+  // is not positive (opticalProperties.f95:1719-1722, counted in nBad, monteCarloRadiativeTransfer.f95:562-563); the kernels
+  // here find cells from positions in places (block walk, clear-air flight, layer skipping), keep face distances in float,
+  // and a table may hand out a NaN (section 8) -- so every loop carries a bound of its own instead of an argument about
+  // rounding: a photon that exceeds one is dropped and counted in *bad (fate 3), as the reference counts nBad.
+  unsigned long long *bad;        // photons (and radiance rays) dropped by a bound; host-visible
+  unsigned maxEvents;             // legs per photon
+  unsigned maxEventsNaN;          // legs a photon may go on with a direction that is NaN
+  unsigned watchdog;              // loop iterations of a wave in which none of its lanes started a leg, took a photon or was refused one
+  float rayMaxLen;                // radiance: no view ray is longer than (zMax - z0) / min |mu| (geometry)
+  int legacyTies;                 // TEST ONLY (MCBRAT_TEST_LEGACY_TIES): bit 0 / 1 / 2 re-enable the block walk's tie handling from before the
+                                  // fixes of soak seeds 168 / 71 / 763 (no clamp to the block left / move along a NaN / span bits outlive the fold)
+  unsigned ldsBytes;              // dynamic LDS of the launch (-DMCBRAT_POISON fills it before the kernel initialises its part)
   // debug / measurement
   mcbrat_fate *fates;             // non-null: record per-photon fate (index = photon index)
   unsigned long long *counters;   // non-null: event counters

@@ -214,14 +214,22 @@ class Integrator:
             self._check(self._lib.mcbrat_set_walk_options(self._ctx, int(layerSkip), int(blockWalk)))
 
     def walkMode(self):
+        """The walk a flux run of the loaded domain uses (decided by the library's launch plan, mcbrat_get_walk_mode)."""
         m = int(self._lib.mcbrat_get_walk_mode(self._ctx))
         return {"layerSkip": bool(m & 1), "blockWalk": bool(m & 2), "clearAirFlight": bool(m & 4)}
+
+    def badPhotons(self):
+        """Photons dropped by a loop bound of the kernels since this integrator was created (the reference's nBad, :562-563)."""
+        return self.counters()["badPhotons"]
 
     def eventThreshold(self):
         return int(self._lib.mcbrat_get_event_threshold(self._ctx))
 
     def setAsync(self, enable=True):
         """Let consecutive computeRadiativeTransfer / resetMoments calls overlap on the GPU (include/mcbrat.h)."""
+        if enable and getattr(self, "_shares_moments", False):
+            raise McbratError("setAsync: this integrator accumulates into a moment array it shares with other integrators "
+                              "(SpectralRun); their finish kernels are only ordered in synchronous mode")
         self._check(self._lib.mcbrat_set_async(self._ctx, int(bool(enable))))
 
     def synchronize(self):

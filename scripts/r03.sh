@@ -1,0 +1,65 @@
+#!/bin/bash
+# round 3: steps run on the GPU box, selected by name (one script instead of one file per gpurun call):
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash scripts/r03.sh tests poison base'
+# Every step writes under gpurun_out/r03/ with a time stamp in the file name, so that a failing log is never overwritten.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/r03
+mkdir -p $OUT
+cd $ROOT
+ts() { date +%m%d_%H%M%S; }
+
+step_tests() {  # the whole GPU suite, one process
+  local log=$OUT/tests_$(ts).log
+  timeout -k 10 900 python -m pytest tests -q -m gpu -x ${PYTEST_ARGS:-} > $log 2>&1; local rc=$?
+  tail -5 $log; grep -n "FAILED\|Timeout\|^E  " $log | head -20 | cut -c1-300
+  echo "tests rc=$rc log=$log"; return $rc
+}
+step_bounds() {  # the tests that drive the kernels into their loop bounds
+  local log=$OUT/bounds_$(ts).log
+  timeout -k 10 600 python -m pytest tests/test_gpu_bounds.py -v -s -m gpu > $log 2>&1; local rc=$?
+  grep -n "PASSED\|FAILED\|Timeout\|^E  \|legacy ties" $log | head -40 | cut -c1-300; tail -3 $log
+  echo "bounds rc=$rc log=$log"; return $rc
+}
+step_poison() {  # the 60-seed in-process radiance run ONCE under the audit build (LDS and fresh device memory filled with 0xff)
+  local log=$OUT/poison_$(ts).log
+  MCBRAT_LIB=$ROOT/ab/libmcbrat_poison.so MCBRAT_FLIGHT_FUZZ=60 timeout -k 10 600 python -m pytest tests/test_gpu_intensity.py -v -m gpu > $log 2>&1; local rc=$?
+  grep -c PASSED $log; grep -n "FAILED\|Timeout\|^E  " $log | head -20 | cut -c1-300; tail -2 $log
+  echo "poison rc=$rc log=$log"; return $rc
+}
+step_poison_all() {  # the rest of the suite under the audit build
+  local log=$OUT/poison_all_$(ts).log
+  MCBRAT_LIB=$ROOT/ab/libmcbrat_poison.so timeout -k 10 900 python -m pytest tests -q -m gpu --deselect tests/test_gpu_intensity.py > $log 2>&1; local rc=$?
+  tail -5 $log; grep -n "FAILED\|Timeout\|^E  " $log | head -20 | cut -c1-300
+  echo "poison_all rc=$rc log=$log"; return $rc
+}
+step_base() {  # development timing of the three workloads (not the judged bench)
+  local log=$OUT/base_$(ts).log
+  { python scripts/quick_bench.py --case step --thr 16 --reps 5 --counters
+    python scripts/quick_bench.py --case landsat --ppb 1000000 --batches 100 --thr 20 --reps 3 --counters
+    python scripts/quick_bench.py --case radar --ppb 1000000 --batches 100 --thr 24 --reps 3; } > $log 2>&1
+  grep "^case\|lanes/phase" $log | cut -c1-330
+  echo "base log=$log"
+}
+step_ab() {  # A/B of libraries in ab/: scripts/r03.sh ab <case> <thr> lib1 lib2 ...  (case: step | landsat | radar)
+  local case=$1 thr=$2; shift 2
+  local log=$OUT/ab_${case}_$(ts).log
+  local args="--case $case --thr $thr --reps 3"
+  [ "$case" != step ] && args="$args --ppb 1000000 --batches 100"
+  for lib in "$@"; do
+    echo "== $lib" >> $log
+    MCBRAT_LIB=$ROOT/ab/$lib python scripts/quick_bench.py $args ${QB_ARGS:-} >> $log 2>&1
+  done
+  grep "^==\|^case\|lanes/phase" $log | cut -c1-330
+  echo "ab log=$log"
+}
+
+rc=0
+while [ $# -gt 0 ]; do
+  s=$1; shift
+  case $s in
+    ab) step_ab "$@"; break ;;
+    *) step_$s || { rc=$?; echo "step $s failed (rc=$rc): stopping"; break; } ;;
+  esac
+done
+exit $rc

@@ -7,9 +7,45 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+GPU_DEFAULT_TIMEOUT = 300  # seconds; tests that need less or more carry their own @pytest.mark.timeout
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than a few seconds on CPU")
     # (pytest-timeout registers this itself where it is installed; declared here so that the marks are known without it)
     config.addinivalue_line("markers", "timeout: per-test time limit (pytest-timeout): a kernel that never ends fails its test")
+    config.addinivalue_line("markers", "allow_bad_photons: the test drives a kernel into one of its loop bounds on purpose")
+
+
+def pytest_collection_modifyitems(config, items):
+    """EVERY GPU test has a time limit: those without a mark of their own get the default, so that a kernel that never
+    ends fails its test instead of stalling the run (the kernels are bounded by construction, DESIGN.md section 4.7 --
+    this is the second line of defence)."""
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(GPU_DEFAULT_TIMEOUT, method="thread"))
+
+
+@pytest.fixture(autouse=True)
+def _no_photon_dropped_by_a_loop_bound(request):
+    """Every integrator a GPU test finalises must report badPhotons == 0 (include/mcbrat.h: photons dropped because a
+    loop bound of the kernels was reached), unless the test provokes a bound on purpose (allow_bad_photons)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from mcbrat3d_amd import integrator as I
+    orig, seen = I.Integrator.finalize, []
+
+    def finalize(self):
+        if getattr(self, "_ctx", None):
+            seen.append(int(self.counters()["badPhotons"]))
+        orig(self)
+
+    I.Integrator.finalize = finalize
+    try:
+        yield
+    finally:
+        I.Integrator.finalize = orig
+    if request.node.get_closest_marker("allow_bad_photons") is None:
+        assert all(b == 0 for b in seen), "photons dropped by a loop bound: %r" % (seen,)

@@ -225,19 +225,8 @@ def test_block_walk_is_run_to_run_bitwise_and_split_independent(M):
     integ.finalize()
 
 
-# seeds the soak runs of this test found bugs with, kept whatever FUZZ is: 168 (a leg through an edge of a block: two position
-# look-ups that both rounded backwards handed the lane to and fro for ever), 122 (a collision booked in the vacuum cell next door)
-SOAK_FINDS = (122, 168)
-
-
-@pytest.mark.timeout(120, method="thread")
-@pytest.mark.parametrize("seed", sorted(set(range(FUZZ)) | set(SOAK_FINDS)))
-def test_random_box_media_against_face_by_face_kernel(M, seed):
-    """Differential test: random small domains painted with random boxes of one extinction value (some spanning a
-    whole periodic axis, vacuum among them, one cell wide in x or y now and then), equal or stretched spacing, random
-    sun and surface, with and without roulette: the block walk (forced where blocks are small) against the face-by-face
-    kernel on the same Philox streams.  Identity is asserted up to ten scatterings (long histories are chaotic)."""
-    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+def random_box_case(seed):
+    """The random box medium of seed `seed`: (case, mu0, phi0, useRussianRoulette)."""
     rng = np.random.default_rng(4200 + seed)
     nx, ny, nz = int(rng.integers(1, 13)), int(rng.integers(1, 7)), int(rng.integers(1, 13))
     def edges(n, stretched, origin):
@@ -260,6 +249,24 @@ def test_random_box_media_against_face_by_face_kernel(M, seed):
                                  legendre=[cases.hg_legendre(float(rng.uniform(0.0, 0.9)), 24)])])
     mu0, phi0 = float(rng.choice([1.0, rng.uniform(0.05, 1.0)])), float(rng.uniform(0.0, 360.0))
     rr = bool(rng.integers(0, 2))
+    return case, mu0, phi0, rr
+
+
+# seeds the soak runs of this test found bugs with, kept whatever FUZZ is: 168 (a leg through an edge of a block: two position
+# look-ups that both rounded backwards handed the lane to and fro for ever), 122 (a collision booked in the vacuum cell next door)
+SOAK_FINDS = (122, 168)
+
+
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("seed", sorted(set(range(FUZZ)) | set(SOAK_FINDS)))
+def test_random_box_media_against_face_by_face_kernel(M, seed):
+    """Differential test: random small domains painted with random boxes of one extinction value (some spanning a
+    whole periodic axis, vacuum among them, one cell wide in x or y now and then), equal or stretched spacing, random
+    sun and surface, with and without roulette: the block walk (forced where blocks are small) against the face-by-face
+    kernel on the same Philox streams.  Identity is asserted up to ten scatterings (long histories are chaotic)."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case, mu0, phi0, rr = random_box_case(seed)
+    nx, ny, nz = len(case["xe"]) - 1, len(case["ye"]) - 1, len(case["ze"]) - 1
     n = 20000
     photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
     out = {}

@@ -248,6 +248,7 @@ def test_column_count_not_a_multiple_of_four(M):
     assert np.array_equal(b["means"], a["means"])
 
 
+@pytest.mark.timeout(120, method="thread")
 @pytest.mark.parametrize("seed", range(FUZZ))
 def test_random_fields_against_face_by_face_walk(M, seed):
     """Differential test: random box clouds, random background (vacuum, thin, thick), equal or stretched spacing, one or two
@@ -271,6 +272,7 @@ def test_random_fields_against_face_by_face_walk(M, seed):
         assert abs(b["means"][0] + b["means"][2] + (1.0 - case["albedo"]) * b["means"][1] - 1.0) < 4.0 / np.sqrt(n)
 
 
+@pytest.mark.timeout(120, method="thread")
 @pytest.mark.parametrize("seed", range(FUZZ))
 def test_random_layerings_against_face_by_face_walk(M, seed):
     """Differential test on random LAYERINGS: every layer is, at random, vacuum, a haze of one extinction value, broken
@@ -315,6 +317,7 @@ def test_random_layerings_against_face_by_face_walk(M, seed):
         assert abs(b["means"][0] + b["means"][2] + (1.0 - alb) * b["means"][1] - 1.0) < 4.0 / np.sqrt(n)
 
 
+@pytest.mark.timeout(120, method="thread")
 @pytest.mark.parametrize("seed", range(FUZZ))
 def test_random_thermal_fields_against_face_by_face_walk(M, seed):
     """Differential test with the emission source (photons start anywhere, in marked cells too, in every direction; emission

@@ -257,6 +257,7 @@ def test_radiance_is_independent_of_the_tally_mode(M):
     assert np.allclose(out[0][8:8 + 3], out[1][8:8 + 3], rtol=2e-3)
 
 
+@pytest.mark.timeout(120, method="thread")
 @pytest.mark.parametrize("seed", range(6))
 def test_ray_buffer_on_random_domains(M, seed, monkeypatch):
     """Random small domains (equal or stretched spacing, random clear layers, one or two components, random views
@@ -301,6 +302,7 @@ def test_ray_buffer_on_random_domains(M, seed, monkeypatch):
 FUZZ = int(__import__("os").environ.get("MCBRAT_FLIGHT_FUZZ", "8"))  # seeds of the random differential test (raise it for a soak run)
 
 
+@pytest.mark.timeout(120, method="thread")
 @pytest.mark.parametrize("seed", range(FUZZ))
 def test_random_domains_radiance_against_the_oracle(M, seed):
     """Radiances of random small domains (equal or stretched spacing, clear layers, one or two components, random views,
@@ -361,6 +363,9 @@ def random_radiance_case(seed):
     if rng.random() < 0.5:
         comps.append(dict(ext=rng.uniform(0.0, 0.2, nz), ssa=np.ones(nz), pfIndex=np.ones(nz, np.int32),
                           legendre=[np.array([0.0, 0.1], np.float32)]))
+    for comp in comps:  # (every component's table, not just the first: the premise of this test is that none holds a NaN)
+        for leg in comp["legendre"]:
+            assert not np.isnan(O.inverse_table_legendre(np.asarray(leg, np.float32), 9001)).any()
     case = dict(name="radiance%d" % seed, xe=xe, ye=ye, ze=ze, albedo=float(rng.choice([0.0, 0.4])), components=comps)
     rr = bool(rng.integers(0, 2))
     ndir = int(rng.integers(1, 4))

@@ -152,6 +152,7 @@ def test_irregular_columns_with_clear_runs(M):
     assert np.all(np.abs(means[1] - means[0]) < 2.5e-3), (means[1], means[0])
 
 
+@pytest.mark.timeout(120, method="thread")
 @pytest.mark.parametrize("seed", range(FUZZ))
 def test_random_domains_against_face_by_face_walk(M, seed):
     """Differential test on random small domains: random grid spacing (equal or stretched), random pattern of
