@@ -55,6 +55,9 @@ WORKLOADS = {
     # config 5: optically thick, omega0 = 0.9, roulette-heavy; not a headline line, kept for its parity record
     "radarLike128": dict(make=lambda: cases.radar_like(), mu0=0.5, phi0=30.0, ppb=1000000, batches=100,
                          cpu=4000000, parity=100000000),
+    # config 4: broadband thermal emission, homogeneous isothermal 20x20x20, 16 wavelengths 8-12 um, every
+    # wavelength's optics and emission CDF resident on the device, 1e8 photons per step split over the wavelengths on the device
+    "homogLW20x16": dict(kind="lw", ppb=1000000, batches=100, cpu=8000000),
 }
 
 
@@ -121,15 +124,15 @@ def z_scores(g, ge, r, re):
     return (np.asarray(g) - np.asarray(r)) / np.sqrt(np.asarray(ge) ** 2 + np.asarray(re) ** 2 + 1e-30)
 
 
-def parity_block(stats, batches, cols, prof, ccnt, ctot):
+def parity_block(stats, batches, cols, prof, ccnt, ctot, flux=1.0):
     """z = (GPU - REF) / sqrt(sigma_GPU^2 + sigma_REF^2), sigma from the batch variance
     (the driver's estimator, monteCarloDriver.f95:1188-1219), over the domain means, every column flux and every
     level of the absorption (heating) profile; pass = max |z| < max(4, sqrt(2 ln N) + 1) over N bins (the largest of N
     unit normals grows like sqrt(2 ln N)) and |mean z| < 0.2."""
     from oracle import oracle as O
-    m_ref, e_ref = O.batch_statistics(batches)
-    c_ref, ce_ref = O.batch_statistics(cols)
-    p_ref, pe_ref = O.batch_statistics(prof)
+    m_ref, e_ref = O.batch_statistics(batches, solar_flux=flux)
+    c_ref, ce_ref = O.batch_statistics(cols, solar_flux=flux)
+    p_ref, pe_ref = O.batch_statistics(prof, solar_flux=flux)
     g = np.array([stats["meanFluxUp"], stats["meanFluxDown"], stats["meanFluxAbsorbed"]])
     ge = np.array([stats["meanFluxUp_StdErr"], stats["meanFluxDown_StdErr"], stats["meanFluxAbsorbed_StdErr"]])
     z = z_scores(g, ge, m_ref, e_ref)
@@ -164,9 +167,22 @@ def pmc_record(workload):
         return json.load(f).get(workload, {})
 
 
-def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False, block_walk=True):
+def kernel_name(walk, thermal=False, lds_grid=None):
+    """The tracing kernel a flux run of this walk mode launches (mcbrat_api.hip: launch_trace)."""
+    if walk.get("blockWalk"):
+        return "trace_block_kernel (mcbrat_blockwalk.hip: block walk, grid + tallies + tables in LDS%s)" % (", thermal source" if thermal else "")
+    return "trace_kernel (mcbrat_kernels.hip: %s%s%s)" % (
+        "layer-skipping walk" if walk.get("layerSkip") else "face-by-face walk",
+        " + clear-air flight" if walk.get("clearAirFlight") else "", ", thermal source" if thermal else "")
+
+
+def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False, block_walk=True, walk=None, thermal=False):
     bpp = algorithmic_bytes_per_photon(cnt, per_step, nc)
     achieved = bpp * per_step / (launch_ms * 1e-3) / 1e9
+    # the walks that skip faces (block walk, layer skipping, clear-air flight) never stop at the cell faces whose 4 bytes
+    # the algorithmic figure counts: the same rate on the bytes such a kernel can touch at all
+    skips = bool(walk and (walk.get("blockWalk") or walk.get("layerSkip")))
+    touched = bpp - (4.0 * cnt["crossings"] / per_step if skips else 0.0)
     rec = pmc_record(workload)
     if workload == "i3rcStepCloud" and not block_walk:
         rec = {}  # (the counters on file are the block-walk kernel's: they do not describe the face-by-face run)
@@ -175,12 +191,15 @@ def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False, block
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "achieved_is": "algorithmic bytes (SURVEY.md 8d) / kernel time: an equivalent rate, not HBM utilisation",
            "measured_hbm_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic is not None else None,
-           "algorithmic_bytes_per_photon": bpp, "kernel": "trace_kernel", "kernel_ms_per_launch": launch_ms,
+           "frac_on_touched_bytes": touched * per_step / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "touched_bytes_per_photon": touched,
+           "algorithmic_bytes_per_photon": bpp, "kernel": kernel_name(walk or {"blockWalk": block_walk and workload == "i3rcStepCloud"}, thermal),
+           "kernel_ms_per_launch": launch_ms,
            "events_per_photon": {k: v / per_step for k, v in cnt.items() if k in (
                "legs", "crossings", "collisions", "absorbEvents", "topExits", "surfaceHits", "rouletteKills", "rouletteSurvivals")},
            "lanes_per_walk_iteration": cnt["walkLanes"] / max(1, cnt["walkIterations"]),
            "lanes_per_event_phase": cnt["eventLanes"] / max(1, cnt["eventPhases"]),
-           "binding_resource": "valu_issue" if (workload == "i3rcStepCloud" or rec.get("wave_time_waiting", 1.0) < 0.4) else "l2_requests",
+           "binding_resource": ("valu_issue" if (workload == "i3rcStepCloud" or rec.get("wave_time_waiting", 1.0) < 0.4) else "l2_requests") if rec else None,
            "note": "working set is cache / LDS resident: HBM is not what binds (see valu); DESIGN.md section 5"
                    + ("; --pipeline: kernel durations include waiting for compute units held by the previous launch" if pipeline else "")}
     if rec.get("valu_insts_per_launch"):
@@ -241,6 +260,49 @@ def secondary_workload(M, new_rng, device, dist, rank, world, name="landsatLike1
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # Strong scaling (north_star: ">= 6x scaling 1 -> 8 GPUs at 1e8 photons"): ONE job of per_step photons whose batches
+    # are split over the ranks as the reference's driver splits its work units (monteCarloDriver.f95:665-880), moments
+    # all-reduced at the end.  With one rank the same job cut into the per-GPU shares of 2, 4 and 8 ranks is timed launch
+    # by launch: a launch ends with its longest photon history, so a smaller share runs at a lower rate, and the ratio of
+    # the two launch times is the speed-up that share would give (the all-reduce of 17 MB over xGMI adds about a millisecond).
+    from mcbrat3d_amd import driver as _driver
+    strong = None
+
+    def strong_step(i, share_of):
+        lo, mine = _driver.split_batches(w["batches"], rank if share_of == world else 0, share_of)
+        rng.nextPhotonId = (10 ** 6 + i) * per_step + lo * w["ppb"]
+        photons.currentPhoton = 1
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, rng, photons, w["ppb"], mine)
+        if dist is not None:
+            dist.all_reduce(moments, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        return integ.lastTraceMs()
+
+    if world > 1:
+        strong_step(0, world)
+        dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            strong_step(1 + i, world)
+        dist.barrier(); torch.cuda.synchronize()
+        dts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(dts, op=dist.ReduceOp.MAX)
+        strong = {"job_photons": per_step, "n_gpus": world, "value": per_step * steps / float(dts.item()), "unit": "photons/s",
+                  "ms_per_job": 1e3 * float(dts.item()) / steps}
+    else:
+        shares = {}
+        for n in (1, 2, 4, 8):
+            strong_step(0, n)  # warm
+            t1 = time.perf_counter()
+            km = sum(strong_step(1 + i, n) for i in range(2))
+            shares[n] = {"photons_per_launch": _driver.split_batches(w["batches"], 0, n)[1] * w["ppb"], "ms_per_launch": 1e3 * (time.perf_counter() - t1) / 2, "kernel_ms": km / 2}
+        t1ms = shares[1]["ms_per_launch"]
+        strong = {"job_photons": per_step, "n_gpus": 1, "per_gpu_share_timed_on_one_gpu": shares,
+                  "projected_speedup": {str(n): t1ms / shares[n]["ms_per_launch"] for n in (2, 4, 8)},
+                  "projected_photons_per_s": {str(n): per_step / (shares[n]["ms_per_launch"] * 1e-3) for n in (1, 2, 4, 8)},
+                  "note": "projection from one GPU: time of the share a rank would trace (1/N of the job in one synchronous "
+                          "launch, finish kernels included), all-reduce not included (17 MB over xGMI)"}
     res = None
     if rank == 0:
         integ.bindMoments(0)
@@ -248,14 +310,143 @@ def secondary_workload(M, new_rng, device, dist, rank, world, name="landsatLike1
         integ.computeRadiativeTransfer(dom, rng, photons, w["ppb"], 10)
         cnt = integ.counters()
         integ.enableCounters(False)
-        rl = roofline_block(name, cnt, w["ppb"] * 10, len(dom.components), kms / steps * 0.1)
+        rl = roofline_block(name, cnt, w["ppb"] * 10, len(dom.components), kms / steps * 0.1, walk=integ.walkMode())
         res = {"workload": "%s %dx%dx%d, %d photons/GPU/step" % (name, dom.numX, dom.numY, dom.numZ, per_step),
                "value": world * per_step * steps / dt, "unit": "photons/s", "n_gpus": world, "steps": steps,
                "ms_per_step": 1e3 * dt / steps, "kernel_ms_per_launch": kms / steps,
                "algorithmic_bytes_per_photon": rl["algorithmic_bytes_per_photon"], "roofline_frac": rl["frac"],
-               "roofline": rl, "event_threshold": integ.eventThreshold()}
+               "roofline": rl, "event_threshold": integ.eventThreshold(), "strong_scaling": strong,
+               "bad_photons": integ.badPhotons()}
     integ.finalize()
     return res
+
+
+def lw_bench(a, M, torch, dist, dev, rank, local_rank, world, rehearse):
+    """--workload homogLW20x16 (BASELINE.json configs[3]): the reference's thermal broadband loop
+    (monteCarloDriver.f95:304-449 set-up pass, :889-1085 worker loop; emission_weightingNEW
+    emissionAndBroadBandWeights.f95:424-550, getFrequencyDistr :552-572, newPhotonStream_BBEmission
+    monteCarloIllumination.f95:431-522) with every wavelength's optics, inverse tables and emission CDF resident on the
+    device (mcbrat3d_amd.broadband.SpectralRun).  One step = 1e8 photons per GPU: the photon split over the 16
+    wavelengths on the device, then every wavelength's photons in batches of 1e6; nothing is uploaded inside the
+    timed loop.  Weak scaling over ranks; one all-reduce of the shared moment array per step."""
+    from mcbrat3d_amd import broadband, driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    from tests import stats as tstats
+    w = WORKLOADS[a.workload]
+    cs = tstats.lw_cases()
+    doms = [cases.product_domain(c) for c in cs]
+    nx, ny, nz = doms[0].numX, doms[0].numY, doms[0].numZ
+    t_setup = time.perf_counter()
+    run = broadband.SpectralRun(M, doms, device=local_rank, minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True)
+    for it in run.integrators:
+        it.setTuning(eventThreshold=a.event_threshold)
+    flux = run.prepare_thermal(tstats.LW_SURFACE_TEMP)  # set-up pass + uploads, once, outside the timed region
+    t_setup = time.perf_counter() - t_setup
+    moments = torch.zeros(8 + 2 * run.first.momentsLength(), dtype=torch.float64, device=dev)
+    run.bindMoments(moments.data_ptr())
+    ppb, nb = w["ppb"], w["batches"]
+    per_step = ppb * nb
+    rng = new_RandomNumberSequence(10)
+    launches = [0]
+
+    def step(i):
+        rng.nextPhotonId = (i * world + rank) * per_step
+        run.resetMoments()
+        counts = run.run(ppb, nb, rng, seed=1000 + i * world + rank)
+        kms = sum(it.lastTraceMs() for it in run.integrators)  # (of each wavelength's last call; see launches_per_step)
+        launches[0] = int(sum((c // ppb) > 0 for c in counts) + sum((c % ppb) > 0 for c in counts))
+        if dist is not None:
+            dist.all_reduce(moments, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        return kms
+
+    def sync():
+        for it in run.integrators:
+            it.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    out = None
+    if rank == 0:
+        stats = driver.statistics(driver.unpack_moments(moments.cpu().numpy(), nx, ny, nz), solarFlux=flux)
+        reduced_photons = int(stats["totalPhotons"])
+        if world > 1:  # parity is quoted on one rank's 1e8 photons
+            run.bindMoments(0)
+        # untimed: one step with every wavelength's photons in ONE call each: tracing-kernel time per step (HIP events around
+        # each tracing kernel, summed over the 16 wavelengths) and, from the instrumented instantiation, the event counters
+        def one_call_per_wavelength(counters):
+            for it in run.integrators:
+                it.enableCounters(counters)
+            run.resetMoments()
+            rng.nextPhotonId = 10 ** 12
+            run.run(per_step, 1, rng, seed=77)
+            return sum(it.lastTraceMs() for it in run.integrators)
+        one_call_per_wavelength(False)
+        launch_ms = one_call_per_wavelength(False)
+        one_call_per_wavelength(True)
+        cnt = None
+        for it in run.integrators:
+            c = it.counters()
+            cnt = c if cnt is None else {k: cnt[k] + v for k, v in c.items()}
+        for it in run.integrators:
+            it.enableCounters(False)
+        walk = run.first.walkMode()
+        rl = roofline_block(a.workload, cnt, per_step, 1, launch_ms, walk=walk, thermal=True)
+        rl["launches"] = "one per wavelength (16): kernel_ms_per_launch is their sum for one step's 1e8 photons"
+        out = {"metric": "photons/sec", "value": world * per_step * a.steps / elapsed, "unit": "photons/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
+               "config": {"workload": "%s: broadband thermal emission, %dx%dx%d homogeneous isothermal (280 K, surface 300 K, albedo 0.1, "
+                                      "ext 5 /km, omega0 0.5, HG g 0.85), 16 wavelengths 8-12 um resident on the device, %d photons/GPU/step "
+                                      "split over the wavelengths on the device, batches of %d" % (a.workload, nx, ny, nz, per_step, ppb),
+                          "photons_per_step_per_gpu": per_step, "parallelism": "photon batches sharded over %d GPU(s)" % world,
+                          "world_size": world, "photons_in_reduced_moments_last_step": reduced_photons,
+                          "kernel_launches_per_step": launches[0], "setup_and_upload_s_once": t_setup,
+                          "emitted_flux_W_m2": flux, "event_threshold": run.first.eventThreshold(), "walk": walk,
+                          "bad_photons": int(sum(it.badPhotons() for it in run.integrators)),
+                          **({"rehearsal": "gloo, all ranks on cuda:0 -- not a measurement"} if rehearse else {})},
+               "roofline": rl}
+        if not a.no_cpu_baseline:
+            cores = max(1, min(a.cpu_cores, len(os.sched_getaffinity(0))))
+            n_core = a.cpu_photons_per_core or w["cpu"]
+            t = time.time()
+            rows, cflux, ccnt, busy = tstats.oracle_lw_run(n_core, CPU_BATCH, cores)
+            ctot = n_core * cores
+            cb = dict(value=ctot / busy, unit="photons/s", cores=cores, kind="port",
+                      sample="%d photons/core x %d cores of the same workload (every core the whole spectrum, its own MT stream: "
+                             "wavelength per photon by getFrequencyDistr, batches of %d), oracle in MT mode (%.1f s wall)"
+                             % (n_core, cores, CPU_BATCH, time.time() - t))
+            cal = os.path.join(ROOT, "profiles", "cpu_calibration.json")
+            if os.path.exists(cal):
+                with open(cal) as f:
+                    rec = json.load(f)
+                cb["calibration_r"] = rec["r"]
+                cb["reference_equivalent"] = cb["value"] / rec["r"]
+                cb["calibration_source"] = rec["source"] + " (measured on the step cloud; applied to this workload as a proxy)"
+            out["cpu_baseline"] = cb
+            if world > 1:
+                run.resetMoments(); rng.nextPhotonId = 5 * 10 ** 12
+                run.run(ppb, nb, rng, seed=5)
+                stats = driver.statistics(driver.unpack_moments(run.moments(), nx, ny, nz), solarFlux=flux)
+            assert abs(cflux - flux) <= 1e-9 * abs(flux), (cflux, flux)  # both sides built the same spectrum
+            out["parity"] = parity_block(stats, rows["means"], rows["columns"], rows["profile"], ccnt, ctot, flux=flux)
+    run.finalize()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def free_port():
@@ -312,7 +503,7 @@ def dry_run(a, rank, world):
     if rank == 0:
         print(json.dumps({"metric": "photons/sec", "value": 0.0, "unit": "photons/s", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": 1e3 * float(tt.item()) / max(1, a.steps), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic", "dry_run": True,
+                          "scaling": a.scaling, "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic", "dry_run": True,
                           "config": {"workload": a.workload, "world_size": dist.get_world_size(), "backend": "gloo",
                                      "ranks_seen": [int(x) - 1 for x in seen.tolist()],
                                      "photons_all_ranks_per_step": int(buf[0].item())}}), flush=True)
@@ -341,6 +532,9 @@ def main():
     ap.add_argument("--pipelined-extra", action="store_true",
                     help="after the timed steps, run them once more with overlapping calls and report that rate as an "
                          "untimed extra in config (not in the default run: its kernel launches would enter a profiler's averages)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, the driver's contract): every rank traces the workload's photons per step; strong: the "
+                         "step's photons are one fixed job whose batches are split over the ranks (monteCarloDriver.f95:665-880)")
     ap.add_argument("--dry-run", action="store_true", help="rehearse launcher + collective on CPU (gloo), no tracing")
     a = ap.parse_args()
 
@@ -398,6 +592,12 @@ def main():
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
 
     w = WORKLOADS[a.workload]
+    if w.get("kind") == "lw":
+        lw_bench(a, M, torch, dist, dev, rank, local_rank, world, rehearse)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     a.cpu_photons_per_core = a.cpu_photons_per_core or w["cpu"]
     a.parity_photons = a.parity_photons or w["parity"]
     case = w["make"]()
@@ -415,21 +615,36 @@ def main():
     rng = new_RandomNumberSequence(10)
     torch_stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def step(i):
-        # rank r traces photon ids [ (i*world + r) * per_step, +per_step ): disjoint over ranks and steps
-        rng.nextPhotonId = (i * world + rank) * per_step
+    reduce_events = []  # (start, end) CUDA events around every all-reduce of the timed steps
+
+    def step(i, timed=False):
+        # weak scaling: rank r traces photon ids [ (i*world + r) * per_step, +per_step ): disjoint over ranks and steps
+        # strong scaling: the step's per_step photons are cut into batches and rank r takes its contiguous share of them
+        if a.scaling == "strong":
+            lo, mine = driver.split_batches(nb, rank, world)
+            rng.nextPhotonId = i * per_step + lo * ppb
+        else:
+            lo, mine = 0, nb
+            rng.nextPhotonId = (i * world + rank) * per_step
         photons.currentPhoton = 1
         integ.resetMoments()
-        integ.computeRadiativeTransfer(dom, rng, photons, ppb, nb)
+        if mine > 0:
+            integ.computeRadiativeTransfer(dom, rng, photons, ppb, mine)
         if dist is not None:
             if a.pipeline:  # order the all-reduce after this step's moments and the next reset after the all-reduce
                 integ.streamWaitDone(torch_stream)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
+            if ev:
+                ev[0].record()
             dist.all_reduce(moments, op=dist.ReduceOp.SUM)  # sumAcrossProcesses, monteCarloDriver.f95:1151-1166
+            if ev:
+                ev[1].record()
+                reduce_events.append(ev)
             if a.pipeline:
                 integ.waitStream(torch_stream)
             else:
                 torch.cuda.synchronize()
-        return 0.0 if a.pipeline else integ.lastTraceMs()
+        return 0.0 if (a.pipeline or mine == 0) else integ.lastTraceMs()
 
     def sync():
         integ.synchronize()
@@ -446,15 +661,24 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = 0.0
     for i in range(a.steps):
-        kernel_ms += step(a.warmup + i)
+        kernel_ms += step(a.warmup + i, timed=True)
     sync()
     elapsed = time.perf_counter() - t0
     if a.pipeline:
         kernel_ms = integ.lastTraceMs()  # summed over the timed steps (read at the synchronisation above)
+    per_rank_kernel_ms, allreduce_ms = [kernel_ms / a.steps], None
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # diagnostics for the scaling curve: every rank's tracing-kernel time per step and the all-reduce's own duration
+        # (CUDA events on the stream the collective runs on), so that a shortfall can be read off the line itself
+        km = torch.tensor([kernel_ms / a.steps], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(km) for _ in range(world)]
+        dist.all_gather(gathered, km)
+        per_rank_kernel_ms = [float(g.item()) for g in gathered]
+        if reduce_events and not rehearse:
+            allreduce_ms = sum(e0.elapsed_time(e1) for e0, e1 in reduce_events) / len(reduce_events)
 
     # Untimed extra (--pipelined-extra, N = 1): the same K steps with consecutive calls allowed to overlap on
     # the GPU (mcbrat_set_async).  A 1e7-photon launch ends with a tail in which most lanes wait for the last histories
@@ -500,20 +724,23 @@ def main():
         integ.enableCounters(False)
         launch_ms = kernel_ms / a.steps
         out = {
-            "metric": "photons/sec", "value": world * per_step * a.steps / elapsed, "unit": "photons/s",
+            "metric": "photons/sec", "value": (1 if a.scaling == "strong" else world) * per_step * a.steps / elapsed, "unit": "photons/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32/f64",
             "data": "synthetic",
-            "config": {"workload": "%s %dx%dx%d, %d photons/GPU/step as %d batches x %d, omega0=0.99 HG g=0.85 mu0=%g"
-                       % (a.workload, nx, ny, nz, per_step, nb, ppb, w["mu0"]),
-                       "photons_per_step_per_gpu": per_step, "parallelism": "photon batches sharded over %d GPU(s)" % world,
+            "config": {"workload": "%s %dx%dx%d, %d photons/%s/step as %d batches x %d, omega0=0.99 HG g=0.85 mu0=%g"
+                       % (a.workload, nx, ny, nz, per_step, "job" if a.scaling == "strong" else "GPU", nb, ppb, w["mu0"]),
+                       "photons_per_step_per_gpu": per_step // world if a.scaling == "strong" else per_step,
+                       "parallelism": "photon batches sharded over %d GPU(s)" % world,
+                       "kernel_ms_per_step_per_rank": per_rank_kernel_ms, "allreduce_ms_per_step": allreduce_ms,
+                       "bad_photons": integ.badPhotons(),
                        "world_size": dist.get_world_size() if dist is not None else 1,
                        **({"rehearsal": "gloo, all ranks on cuda:0 -- not a measurement"} if rehearse else {}),
                        "photons_in_reduced_moments_last_step": reduced_photons,
                        "pipelined_steps": bool(a.pipeline), "pipelined_photons_per_s_untimed_extra": pipelined_rate,
                        "event_threshold": thr_timed,
                        "walk": integ.walkMode()},
-            "roofline": roofline_block(a.workload, cnt, per_step, nc, launch_ms, a.pipeline, integ.walkMode()["blockWalk"]),
+            "roofline": roofline_block(a.workload, cnt, per_step, nc, launch_ms, a.pipeline, integ.walkMode()["blockWalk"], walk=integ.walkMode()),
         }
         if not a.no_cpu_baseline:
             cb, batches, cols, ccnt, ctot, prof = cpu_baseline(a.workload, a.cpu_photons_per_core, a.cpu_cores)

@@ -178,7 +178,6 @@ int init_lane(mcbrat_ctx *c, int i) {
   HIP_OK(c, hipEventCreate(&L.ev1));
   HIP_OK(c, hipEventCreateWithFlags(&L.evDone, hipEventDisableTiming));
   HIP_OK(c, dev_malloc((void **)&L.dCounter, sizeof(unsigned long long)));
-  HIP_OK(c, hipMemset(L.dCounter, 0, sizeof(unsigned long long)));
   return 0;
 }
 
@@ -233,7 +232,11 @@ int ensure_moments(mcbrat_ctx *c) {
   if (c->dMoments) return 0;
   const size_t n = 8 + 2 * (size_t)moments_len(c);
   HIP_OK(c, dev_malloc((void **)&c->dMomentsOwned, sizeof(double) * n));
-  HIP_OK(c, hipMemset(c->dMomentsOwned, 0, sizeof(double) * n));
+  // (on the stream the finish kernels run on: hipMemset on the null stream is asynchronous for device memory and the
+  // context's streams are non-blocking, so nothing would order a null-stream memset before the first finish kernels)
+  if (init_lane(c, c->cur)) return 1;
+  HIP_OK(c, hipMemsetAsync(c->dMomentsOwned, 0, sizeof(double) * n, c->L().stream));
+  HIP_OK(c, hipStreamSynchronize(c->L().stream));
   c->dMoments = c->dMomentsOwned;
   return 0;
 }
@@ -704,6 +707,12 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
     p.fly = 1; p.flyNbx = c->flyNbx; p.flyNby = c->flyNby; p.extWalk = c->dExtWalk;
     p.flyInvBrickX = (float)(c->flyNbx / p.Lx); p.flyInvBrickY = (float)(c->flyNby / p.Ly);
   }
+#ifdef MCBRAT_DEV_MAIN_ONLY  // development builds (seconds instead of minutes, scripts/kernel_resources.py --main): only the two
+  // instantiations that carry the bench workloads exist -- the step cloud's block walk and the 128x128x64 flux kernel
+  if (block_walk_applies(c, L))
+    return launch_block_s<768, true, false, false, 2>(c, p, block_lds_layout(c->nx, c->ny, c->nz, c->nc, (size_t)p.slabStride, c->nBlocks, (size_t)c->tblTotalFloats).total, nBatches);
+  return launch_trace_e<256, false, 0, false, false, false, false, 3>(c, p, L.lds, nBatches);
+#else
   if (block_walk_applies(c, L)) return launch_block(c, p, L, debug, nBatches);
   // small domains (grid, tables and tallies in LDS): LDS holds two workgroups per CU, and two workgroups of 12 waves
   // (6 per SIMD, 80 VGPRs) beat two of 8 (4 per SIMD, no spills) by 10 % on the step cloud (640 and 896 lanes lose)
@@ -712,6 +721,7 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
     return L.tblLds ? launch_trace_t<768, true, 2, false, false>(c, p, L.lds, nBatches) : launch_trace_t<768, false, 2, false, false>(c, p, L.lds, nBatches);
   if (L.block >= 512) return debug ? launch_trace_b<512, true>(c, p, L, nBatches) : launch_trace_b<512, false>(c, p, L, nBatches);
   return debug ? launch_trace_b<256, true>(c, p, L, nBatches) : launch_trace_b<256, false>(c, p, L, nBatches);
+#endif
 }
 
 int check_ready(mcbrat_ctx *c) {
@@ -797,7 +807,8 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (init_lane(c, 0) || hipEventCreateWithFlags(&c->evExternal, hipEventDisableTiming) != hipSuccess ||
       dev_malloc((void **)&c->dEventCounters, 32 * sizeof(unsigned long long)) != hipSuccess ||
       dev_malloc((void **)&c->dBad, sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(c->dBad, 0, sizeof(unsigned long long)) != hipSuccess ||
+      hipMemsetAsync(c->dBad, 0, sizeof(unsigned long long), c->lane[0].stream) != hipSuccess ||
+      hipStreamSynchronize(c->lane[0].stream) != hipSuccess ||
       hipHostMalloc((void **)&c->hBad, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
     mcbrat_destroy(c);
     return nullptr;

@@ -41,6 +41,32 @@ step_base() {  # development timing of the three workloads (not the judged bench
   grep "^case\|lanes/phase" $log | cut -c1-330
   echo "base log=$log"
 }
+step_bench() {  # the judged line (step cloud + 128x128x64 secondary)
+  local f=$OUT/bench_stepcloud_$(ts)
+  python bench.py ${BENCH_ARGS:-} > $f.json 2> $f.err; local rc=$?
+  python - "$f.json" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r=d["roofline"]; s=d.get("secondary") or {}
+print("value %.4g ms/step %.3f frac %.3f touched %.3f kernel %s" % (d["value"], d["ms_per_step"], r["frac"], r["frac_on_touched_bytes"], r["kernel"][:40]))
+print("bad", d["config"].get("bad_photons"), "parity ok", (d.get("parity") or {}).get("within_thresholds"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
+if s: print("secondary %.4g frac %.3f thr %s strong %s" % (s["value"], s["roofline_frac"], s["event_threshold"], json.dumps(s.get("strong_scaling",{}).get("projected_speedup"))))
+PY
+  echo "bench rc=$rc out=$f.json"; return $rc
+}
+step_bench_lw() {  # config 4
+  local f=$OUT/bench_lw_$(ts)
+  python bench.py --workload homogLW20x16 --steps 5 --warmup 1 ${BENCH_ARGS:-} > $f.json 2> $f.err; local rc=$?
+  tail -3 $f.err
+  python - "$f.json" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r=d["roofline"]
+print("LW value %.4g ms/step %.3f frac %.3f kernel_ms %.3f launches %s" % (d["value"], d["ms_per_step"], r["frac"], r["kernel_ms_per_launch"], d["config"]["kernel_launches_per_step"]))
+print("bad", d["config"].get("bad_photons"), "parity", json.dumps({k:v for k,v in (d.get("parity") or {}).items() if k.startswith(("max_","within","z_domain"))}), "cpu", (d.get("cpu_baseline") or {}).get("value"))
+PY
+  echo "bench_lw rc=$rc out=$f.json"; return $rc
+}
 step_ab() {  # A/B of libraries in ab/: scripts/r03.sh ab <case> <thr> lib1 lib2 ...  (case: step | landsat | radar)
   local case=$1 thr=$2; shift 2
   local log=$OUT/ab_${case}_$(ts).log

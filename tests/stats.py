@@ -102,3 +102,71 @@ def assert_parity(a, b, label, mean_sigma=4.0, bin_sigma=4.0, mean_z=0.2, bin_ma
     if zp.size:
         assert np.max(np.abs(zp)) < bin_sigma, report
     return report
+
+
+# ---- config 4: broadband thermal emission, homogeneous isothermal 20x20x20, 16 wavelengths 8-12 um ----
+LW_LAMBDAS = tuple(float(x) for x in np.linspace(8.0, 12.0, 16))
+LW_SURFACE_TEMP = 300.0
+
+
+def lw_cases(lambdas=LW_LAMBDAS, n=20):
+    """One case per wavelength domain of config 4 (Domain-Files/homogBBDomain.f95:39-66)."""
+    return [cases.homog_lw(n=n, lam=lam) for lam in lambdas]
+
+
+def _lw_worker(args):
+    """The reference's thermal broadband loop with its own generator (the reference-faithful oracle mode): emission
+    weighting per wavelength (emissionAndBroadBandWeights.f95:424-550), the power CDF, one MT uniform per photon for its
+    wavelength (getFrequencyDistr :552-572), then every wavelength's photons in batches (monteCarloDriver.f95:889-1085)."""
+    lambdas, n, seed, proc, total, ppb = args
+    import time
+    from oracle import oracle as O
+    from mcbrat3d_amd import broadband
+    t0 = time.time()
+    cs = lw_cases(lambdas, n)
+    widths = broadband.spectral_widths(list(lambdas))
+    probs, srcs, fl = [], [], []
+    for c, dl in zip(cs, widths):
+        P = cases.oracle_problem(c, nsteps=9001, lw_flag=1.0)
+        vw, frac, f = O.emission_weighting(P, c["temps"].transpose(2, 1, 0).reshape(-1), c["lambda_um"], LW_SURFACE_TEMP, dl)
+        probs.append(P); srcs.append(O.EmissionSource(vw, frac)); fl.append(f)
+    cdf, flux = broadband.emitted_flux_cdf(fl)
+    rng = O.mt_rng([seed, proc, 0])
+    t1 = time.time()
+    counts = O.frequency_distribution(rng, cdf, total)
+    rows, counters = [], None
+    for P, src, cnt in zip(probs, srcs, counts):
+        left = int(cnt)
+        while left > 0:
+            k = min(ppb, left)
+            r = O.compute_radiative_transfer(P, src, rng, k)
+            rows.append((k, np.array([r["meanFluxUp"], r["meanFluxDown"], r["meanFluxAbsorbed"]], np.float64),
+                         np.concatenate([r["fluxUp"], r["fluxDown"], r["fluxAbsorbed"]]).astype(np.float64),
+                         np.asarray(r["absorbedProfile"], np.float64)))
+            counters = r["counters"] if counters is None else {q: counters[q] + v for q, v in r["counters"].items()}
+            left -= k
+    return rows, flux, counters, time.time() - t1, t1 - t0
+
+
+def oracle_lw_run(total_per_proc, ppb, procs, lambdas=LW_LAMBDAS, n=20, seed=10):
+    """Config 4 on the host cores, oracle in MT mode: every process runs the whole spectrum with its own MT stream.
+    -> (dict quantity -> list of (n, values) per batch, spectrally integrated emitted flux, event counters, seconds of
+    the busiest process in the photon loop)."""
+    from oracle import oracle as O
+    O.build()
+    jobs = [(tuple(lambdas), n, seed, p + 1, int(total_per_proc), int(ppb)) for p in range(procs)]
+    if procs == 1:
+        parts = [_lw_worker(jobs[0])]
+    else:
+        with mp.get_context("spawn").Pool(procs) as pool:
+            parts = pool.map(_lw_worker, jobs)
+    rows = [r for part in parts for r in part[0]]
+    counters = {q: sum(part[2][q] for part in parts) for q in parts[0][2]}
+    out = {"means": [(k, a) for k, a, _, _ in rows], "columns": [(k, c) for k, _, c, _ in rows],
+           "profile": [(k, p) for k, _, _, p in rows]}
+    return out, parts[0][1], counters, max(part[3] for part in parts)
+
+
+def lw_mean_err(batches, flux):
+    from oracle import oracle as O
+    return {q: O.batch_statistics(batches[q], solar_flux=flux) for q in QUANTITIES}

@@ -72,3 +72,28 @@ def test_block_walk_and_face_by_face_walk_agree_with_the_mt_oracle(M):
     on = _gpu(M, case, 1.0, 0.0, 100000, 200, tuning=dict(blockWalk=1))
     off = _gpu(M, case, 1.0, 0.0, 100000, 200, seed=78, tuning=dict(blockWalk=0))
     print(stats.assert_parity(on, off, "block walk vs face-by-face walk"))
+
+
+def test_config4_broadband_thermal_agrees_with_the_mt_oracle(M):
+    """BASELINE.json configs[3] at full size on the GPU: homogeneous isothermal 20x20x20, 16 wavelengths 8-12 um resident on the
+    device, 10^8 photons split over the wavelengths on the device (SpectralRun: emission_weightingNEW
+    emissionAndBroadBandWeights.f95:424-550, getFrequencyDistr :552-572, newPhotonStream_BBEmission
+    monteCarloIllumination.f95:431-522) -- against 3.2x10^6 photons of the oracle's reference-faithful mode on the host cores
+    (its own MT streams, the reference's draw order in the thermal launch, its rejection loops): spectrally integrated domain
+    means, every column flux and every level of the heating profile, in W/m2.  (The thermal source itself is restated from
+    source text only -- 'parity unpinned' against the Fortran; this test ties the kernel's launch code
+    to the oracle's independent one statistically, as tests/test_gpu_parity.py does photon by photon in Philox mode.)"""
+    from mcbrat3d_amd import broadband, driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    doms = [cases.product_domain(c) for c in stats.lw_cases()]
+    run = broadband.SpectralRun(M, doms, minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True)
+    flux = run.prepare_thermal(stats.LW_SURFACE_TEMP)
+    run.resetMoments()
+    counts = run.run(10 ** 6, 100, new_RandomNumberSequence(77), seed=3)
+    assert counts.sum() == 10 ** 8 and counts.size == 16 and counts.min() > 10 ** 6
+    st = driver.statistics(driver.unpack_moments(run.moments(), 20, 20, 20), solarFlux=flux)
+    assert sum(it.badPhotons() for it in run.integrators) == 0
+    run.finalize()
+    rows, cflux, _, _ = stats.oracle_lw_run(200000, 100000, 16)
+    assert cflux == pytest.approx(flux, rel=1e-12)
+    print(stats.assert_parity(stats.gpu_mean_err(st), stats.lw_mean_err(rows, cflux), "config 4: broadband thermal 20x20x20, 16 wavelengths"))
