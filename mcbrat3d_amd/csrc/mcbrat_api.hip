@@ -711,6 +711,7 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   // instantiations that carry the bench workloads exist -- the step cloud's block walk and the 128x128x64 flux kernel
   if (block_walk_applies(c, L))
     return launch_block_s<768, true, false, false, 2>(c, p, block_lds_layout(c->nx, c->ny, c->nz, c->nc, (size_t)p.slabStride, c->nBlocks, (size_t)c->tblTotalFloats).total, nBatches);
+  if (debug) return launch_trace_e<256, false, 0, false, true, false, false, 0>(c, p, L.lds, nBatches);
   return launch_trace_e<256, false, 0, false, false, false, false, 3>(c, p, L.lds, nBatches);
 #else
   if (block_walk_applies(c, L)) return launch_block(c, p, L, debug, nBatches);

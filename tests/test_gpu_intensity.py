@@ -306,8 +306,8 @@ FUZZ = int(__import__("os").environ.get("MCBRAT_FLIGHT_FUZZ", "8"))  # seeds of 
 @pytest.mark.parametrize("seed", range(FUZZ))
 def test_random_domains_radiance_against_the_oracle(M, seed):
     """Radiances of random small domains (equal or stretched spacing, clear layers, one or two components, random views,
-    with and without roulette, reflecting surface now and then) against the oracle on the same Philox streams: direction
-    means tightly, pixels against the level of the field (a photon whose history flips moves a few percent of a pixel)."""
+    with and without roulette, reflecting surface now and then) against the oracle on the same Philox streams: over the
+    histories that are identical on both sides, direction means and pixels to 2 %."""
     from oracle import oracle as O
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
     case, rr, mus, phis, mu0, priv = random_radiance_case(seed)
@@ -321,25 +321,43 @@ def test_random_domains_radiance_against_the_oracle(M, seed):
     integ.resetMoments()
     integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n)
     got = integ.reportResults()
-    integ.finalize()
     P = cases.oracle_problem(case, nsteps=9001)
     I = cases.oracle_intensity(case, mus, phis, n_angles=9001, use_russian_roulette=rr, zeta_min=0.3)
-    ref = O.compute_radiative_transfer_intensity(P, O.solar_source(mu0, 40.0), O.philox_rng(SEED, 0), n, I)
+    src = O.solar_source(mu0, 40.0)
+    ref = O.compute_radiative_transfer_intensity(P, src, O.philox_rng(SEED, 0), n, I)
     r = ref["intensity"].reshape(-1, ny, nx).transpose(2, 1, 0)
-    g = got["intensity"]
+    g = got["intensity"].astype(np.float64)
     assert g.shape == r.shape == (nx, ny, ndir)
-    # (a local estimate under a grazing view carries 1 / |mu|: ONE photon whose history flips -- a rounding tie in the optical
-    # depth, the identity tests accept 1.5 % of them -- can move a direction mean by percents.  Soak seed 4280 of 14000:
-    # mu = -0.15, the whole 3.3 % in one pixel, both walks of the product identical.  So: 2 % once the pixel that differs
-    # most is left out, 8 % with it.)
-    assert np.allclose(got["meanIntensity"], ref["meanIntensity"], rtol=8e-2, atol=2e-4), (case["name"], got["meanIntensity"], ref["meanIntensity"])
+    # A local estimate under a grazing view carries 1 / |mu|: ONE photon whose history flips between the two walks -- a
+    # rounding tie in the optical depth; the identity tests accept 1.5 % of them -- can move a direction mean by percents
+    # (soak seed 4280 of 14000: mu = -0.15, the whole 3.3 % in one pixel).  So the flipped histories are FOUND (the photons'
+    # own walk does not depend on the views: a flux run of the same walk, photon by photon, product and oracle) and their
+    # contributions are taken out of both sides: each of them traced again alone, by its photon id.  What is left are
+    # identical histories, and for those the radiances must agree to 2 % of the direction mean -- on the mean and on the
+    # pixels' mean absolute difference -- whatever the view.
+    flux = M.new_Integrator(dom)
+    flux.specifyParameters(minInverseTableSize=9001)
+    flux.setTuning(eventThreshold=24, privateTallies=priv, layerSkip=2, blockWalk=0)  # (the radiance kernels' walk: layers skipped, no flight, no blocks)
+    fg = flux.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+    flux.finalize()
+    fo = O.compute_rt(P, src, O.philox_rng(SEED, 0), n, want_fates=True)["fates"]
+    flipped = np.flatnonzero((fg["fate"] != fo["fate"]) | (fg["ix"] != fo["ix"]) | (fg["iy"] != fo["iy"]) | (fg["iz"] != fo["iz"]) |
+                             (fg["nScatter"] != fo["nScatter"]) | (np.abs(fg["weight"] - fo["weight"]) > 1e-6))
+    assert flipped.size <= 0.03 * n, (case["name"], flipped.size)
+    for i in flipped:
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED, firstPhotonId=int(i)), photons, 1)
+        g -= integ.reportResults()["intensity"].astype(np.float64) / n
+        one = O.compute_radiative_transfer_intensity(P, src, O.philox_rng(SEED, int(i)), 1, I)
+        r = r - one["intensity"].reshape(-1, ny, nx).transpose(2, 1, 0).astype(np.float64) / n
+    integ.finalize()
     for d in range(ndir):
-        diff = g[:, :, d] - r[:, :, d]
-        worst = np.unravel_index(np.argmax(np.abs(diff)), diff.shape)
-        rest = (diff.sum() - diff[worst]) / diff.size
-        assert abs(rest) < 2e-2 * abs(float(ref["meanIntensity"][d])) + 2e-4, (case["name"], d, rest, ref["meanIntensity"][d])
-        scale = float(np.mean(np.abs(r[:, :, d]))) + 1e-6
-        assert np.mean(np.abs(g[:, :, d] - r[:, :, d])) < 0.08 * scale, (case["name"], d, np.mean(np.abs(g[:, :, d] - r[:, :, d])) / scale)
+        level = abs(float(ref["meanIntensity"][d])) + 1e-4
+        assert abs(g[:, :, d].mean() - r[:, :, d].mean()) < 2e-2 * level, (case["name"], d, flipped.size, g[:, :, d].mean(), r[:, :, d].mean())
+        assert np.mean(np.abs(g[:, :, d] - r[:, :, d])) < 2e-2 * (float(np.mean(np.abs(r[:, :, d]))) + 1e-4), \
+            (case["name"], d, flipped.size, np.mean(np.abs(g[:, :, d] - r[:, :, d])) / (float(np.mean(np.abs(r[:, :, d]))) + 1e-4))
+    # (and with every photon in: the flipped ones are a couple of percent of the photons, so are their radiances)
+    assert np.allclose(got["meanIntensity"], ref["meanIntensity"], rtol=0.25, atol=5e-4), (case["name"], got["meanIntensity"], ref["meanIntensity"])
 
 
 def random_radiance_case(seed):
