@@ -115,6 +115,7 @@ program mcbrat_driver
   call check("computeRadiativeTransfer")
   print '(A,I14,A,F10.3,A,ES10.3,A)', " traced ", nDone, " photons, kernel ", lastTraceMilliseconds(mcIntegrator), &
         " ms = ", real(nDone) / (1.e-3 * lastTraceMilliseconds(mcIntegrator)), " photons/s"
+  print '(A,I14)', " photons dropped by a loop bound (the reference's nBad): ", numBadPhotons(mcIntegrator)
 
   ! moments -> mean and standard error (:1188-1228)
   M = momentsLength(mcIntegrator)

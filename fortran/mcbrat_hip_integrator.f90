@@ -27,7 +27,7 @@ module mcbrat_hip_integrator
             resetMoments, getMoments, momentsLength, lastMessage, &
             inverseTableLegendre, lastTraceMilliseconds, setAsynchronous, synchronize, &
             specifyIntensity, setForwardTable, reportIntensity, forwardTableLegendre, &
-            setSurfaceDescription, setWalkOptions, getFrequencyDistr, shareMoments
+            setSurfaceDescription, setWalkOptions, getFrequencyDistr, shareMoments, numBadPhotons
 
   interface
     function mcbrat_create(device) bind(C, name="mcbrat_create") result(ctx)
@@ -174,6 +174,12 @@ module mcbrat_hip_integrator
       import :: c_ptr, c_float
       type(c_ptr), value :: ctx
       real(c_float) :: ms
+    end function
+    function mcbrat_get_counters(ctx, counters) bind(C, name="mcbrat_get_counters") result(rc)
+      import :: c_ptr, c_int, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), dimension(15), intent(out) :: counters   ! mcbrat_counters: 14 event / loop counters, then badPhotons
+      integer(c_int) :: rc
     end function
     function mcbrat_set_walk_options(ctx, layerSkip, blockWalk) bind(C, name="mcbrat_set_walk_options") result(rc)
       import :: c_ptr, c_int, c_int32_t
@@ -431,6 +437,15 @@ contains
     integer, intent(out) :: ierr
     ierr = mcbrat_set_walk_options(this%ctx, merge(1_c_int32_t, 0_c_int32_t, layerSkip), merge(1_c_int32_t, 0_c_int32_t, blockWalk))
   end subroutine setWalkOptions
+  ! computeRT's nBad (Integrators/monteCarloRadiativeTransfer.f95:420, :562-563: photons dropped because their step was not
+  ! positive): here the photons dropped because a loop bound of the kernels was reached, since this integrator was created
+  ! (mcbrat_counters.badPhotons, include/mcbrat.h).  Synchronises.
+  integer(8) function numBadPhotons(this)
+    type(integrator), intent(in) :: this
+    integer(c_int64_t), dimension(15) :: counters
+    numBadPhotons = -1
+    if (mcbrat_get_counters(this%ctx, counters) == 0) numBadPhotons = counters(15)
+  end function numBadPhotons
   ! getFrequencyDistr (src/emissionAndBroadBandWeights.f95:552-572) with the draws made and counted on the device
   subroutine getFrequencyDistr(this, CDF, totalPhotons, iseed, distribution, ierr)
     type(integrator), intent(inout) :: this

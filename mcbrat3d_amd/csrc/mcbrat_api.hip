@@ -1401,7 +1401,7 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     {
       unsigned long long st[16];
       HIP_OK(c, hipMemcpy(st, c->dEventCounters + 16, sizeof(st), hipMemcpyDeviceToHost));
-      const char *names[9] = {"launch", "(unused)", "collideA(pos,optics,absorb,roulette)", "collideB(angle,cos)", "collideC(next_direct)",
+      const char *names[9] = {"launch", "block crossings (block walk)", "collideA(pos,optics,absorb,roulette)", "collideB(angle,cos)", "collideC(next_direct)",
                               "exits(top,surface)", "leg", "walk", "phase-head(jump,column look-up)"};
       double tot = 0;
       for (int i = 0; i < 9; i++) tot += (double)st[i];

@@ -221,6 +221,10 @@ trace_block_kernel(const DevParams p) {
     state = BW_DEAD; \
     atomicAdd(p.bad, 1ull); \
   } while (0)
+#ifdef MCBRAT_STAMPS  // development aid (-DMCBRAT_STAMPS): wave cycles per section of the loop, reported with the event counters
+  __shared__ unsigned long long s_tprev[BLOCK / 64], s_stamp[BLOCK / 64][9];
+  if (lane == 0) { s_tprev[threadIdx.x >> 6] = clock64(); for (int i = 0; i < 9; i++) s_stamp[threadIdx.x >> 6][i] = 0; }
+#endif
   for (unsigned long long unit = blockIdx.x;; unit += gridDim.x) {
     if (unit >= p.nUnits) break;  // workgroup-uniform
     uint32_t batch;
@@ -314,6 +318,7 @@ trace_block_kernel(const DevParams p) {
           }
         }
       }
+      STAMP(5);
       const unsigned long long mDead = __ballot(state == BW_DEAD && more);
       const bool doLaunch = __popcll(mDead) >= p.launchThreshold || idle;
       const unsigned long long want = doLaunch ? mDead : 0ull;
@@ -419,6 +424,7 @@ trace_block_kernel(const DevParams p) {
           }
         }
       }
+      STAMP(0);
       // ---- scattering event, computeRT :703-821 ----
       if (state == BW_COLLIDE) {
         // opticalProperties.f95:1729-1738: the point inside the block where tau is used up.  (Not for a leg whose direction
@@ -479,6 +485,7 @@ trace_block_kernel(const DevParams p) {
           if (u01(r1[1]) >= w) { w = 0.0f; if (DEBUG) cKill++; }
           else { w = 1.0f; if (DEBUG) cSurv++; }
         }
+        STAMP(2);
         if (w <= FLT_MIN) {  // :812
           if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{2, ix + 1, iy + 1, iz + 1, nScat, nLegs, 0.0f};
           state = BW_DEAD;
@@ -503,6 +510,7 @@ trace_block_kernel(const DevParams p) {
 #else
           const float cs = cos_0_pi(ang);
 #endif
+          STAMP(3);
           // next_direct :1921-1948 with (AX, AY)/sqrt(D) = (cos, sin) of a uniform azimuth
           float AX, AY;
           sincos_2pi(uY, AX, AY);
@@ -519,8 +527,10 @@ trace_block_kernel(const DevParams p) {
           dy = dy * D - AY;
           dz = dz * cs - copysignf(fabsf(B), dz * B);
           needLeg = true;
+          STAMP(4);
         }
       }
+      STAMP(4);
       // ---- start the next leg: tau, 1/direction, the block the leg starts in ----
       sinceProgress = (__ballot(needLeg) != 0ull || want != 0ull) ? 0u : sinceProgress + 1u;
       if (sinceProgress > p.watchdog) {  // (wave-uniform; never in a run whose every lane makes progress)
@@ -529,7 +539,7 @@ trace_block_kernel(const DevParams p) {
       }
       // (a photon is allowed maxEvents legs; one with a NaN direction -- see the collision above -- maxEventsNaN: where
       // omega0 = 1 its weight never falls and neither the reference nor the roulette would ever end it)
-      if (needLeg && event >= (dz == dz ? p.maxEvents : p.maxEventsNaN)) { needLeg = false; MCBRAT_BW_DROP(); }
+      if (needLeg && event >= ((dz == dz || w < 1.0f) ? p.maxEvents : p.maxEventsNaN)) { needLeg = false; MCBRAT_BW_DROP(); }
       if (needLeg) {
         event++;
         nLegs++;
@@ -556,6 +566,7 @@ trace_block_kernel(const DevParams p) {
         enterBlock(ix, iy, iz);
         state = BW_MOVE;
       }
+      STAMP(6);
       // ---- block crossings: the cell on the other side of the face, from the position; its block ----
       if (state == BW_CROSS && doCross) {
         const bool yLtX = !NOY && tny < tnx;
@@ -591,6 +602,7 @@ trace_block_kernel(const DevParams p) {
         enterBlock(jx, jy, jz);
         state = BW_MOVE;
       }
+      STAMP(1);
       // wave-uniform exit: nothing alive and every lane has already been refused a new photon
       if (__ballot(state != BW_DEAD || more) == 0ull) break;
 
@@ -627,6 +639,7 @@ trace_block_kernel(const DevParams p) {
           if (isZ && (dz >= 0.0f ? (int)(rz >> 16) == p.nz : (rz & 0xffffu) == 0u)) state = dz >= 0.0f ? BW_TOP : BW_SURFACE;  // :1801-1812
         }
       }
+      STAMP(7);
     }
 
     // flush this unit's private tallies into the batch slab, once
@@ -642,6 +655,9 @@ trace_block_kernel(const DevParams p) {
     __syncthreads();
   }
 
+#ifdef MCBRAT_STAMPS
+  if (DEBUG && p.counters && lane == 0) for (int i = 0; i < 9; i++) atomicAdd(p.counters + 16 + i, s_stamp[threadIdx.x >> 6][i]);
+#endif
   if (DEBUG && p.counters) {
     atomicAdd(p.counters + 0, (unsigned long long)cLegs);
     atomicAdd(p.counters + 1, (unsigned long long)cCross);

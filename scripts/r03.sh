@@ -67,6 +67,16 @@ print("bad", d["config"].get("bad_photons"), "parity", json.dumps({k:v for k,v i
 PY
   echo "bench_lw rc=$rc out=$f.json"; return $rc
 }
+step_soak() {  # the random differential tests with more seeds (SOAK seeds each, default 400), one log per test file
+  local n=${SOAK:-400}
+  for t in test_gpu_flight test_gpu_parity test_gpu_layer_skip test_gpu_block_walk test_gpu_intensity test_gpu_tunings; do
+    local log=$OUT/soak_${t}_$(ts).log
+    MCBRAT_FLIGHT_FUZZ=$n timeout -k 10 1000 python -m pytest tests/$t.py -q -m gpu -k "random" -p no:cacheprovider > $log 2>&1; local rc=$?
+    echo "soak $t ($n seeds) rc=$rc: $(tail -1 $log)"; grep -n "FAILED\|Timeout\|^E  " $log | head -8 | cut -c1-250
+    [ $rc -ne 0 ] && [ $rc -ne 1 ] && return $rc   # (a failed assertion goes on to the next file; a hang or crash stops the step)
+  done
+  return 0
+}
 step_ab() {  # A/B of libraries in ab/: scripts/r03.sh ab <case> <thr> lib1 lib2 ...  (case: step | landsat | radar)
   local case=$1 thr=$2; shift 2
   local log=$OUT/ab_${case}_$(ts).log

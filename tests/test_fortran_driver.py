@@ -177,6 +177,8 @@ def test_fortran_driver_radiance_matches_python_driver(tmp_path):
     pn.write_text(text % (tmp_path / "p.rad"))
     out = subprocess.run([exe, str(fn)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
+    bad = [l for l in out.stdout.splitlines() if "nBad" in l]  # numBadPhotons through the shim: nothing dropped by a loop bound
+    assert bad and int(bad[0].split(":")[-1]) == 0, out.stdout
     driver_cli.main([str(pn)])
     rows = lambda p: np.array([[float(x) for x in l.split()] for l in open(p) if not l.startswith("!")])  # noqa: E731
     f, p = rows(tmp_path / "f.rad"), rows(tmp_path / "p.rad")

@@ -60,6 +60,7 @@ def test_soak_finds_end_with_the_original_tie_handling(M, which, seed, ties, mon
     assert good[2] == 0 and good[3] == 0
     monkeypatch.setenv("MCBRAT_TEST_LEGACY_TIES", str(ties))  # read when the context is created
     monkeypatch.setenv("MCBRAT_WATCHDOG", "50000")             # (the default, 2^20 loop iterations, takes about a second to fire)
+    monkeypatch.setenv("MCBRAT_MAX_EVENTS", "200000")          # (the default, 2^24 legs, takes many seconds for a lone photon to reach)
     old = _run(M, case, mu0, phi0, rr, n, tables, blockWalk=2)
     dropped = old[0]["fate"] == 3
     assert dropped.sum() == old[2] and old[2] == old[3], (dropped.sum(), old[2], old[3])  # the same photons in both calls
