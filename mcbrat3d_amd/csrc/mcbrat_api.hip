@@ -135,7 +135,7 @@ struct mcbrat_ctx {
   // loop bounds of the kernels (DevParams::bad ...) and the count of what they dropped
   unsigned long long *dBad = nullptr;   // device: photons / rays dropped since the context was created
   unsigned long long *hBad = nullptr;   // pinned host copy, refreshed after every launch
-  unsigned maxEvents = 1u << 24, maxEventsNaN = 4096u, watchdog = 1u << 20;  // MCBRAT_MAX_EVENTS, MCBRAT_WATCHDOG
+  unsigned maxEvents = 1u << 24, maxEventsNaN = 1u << 20, watchdog = 1u << 20;  // MCBRAT_MAX_EVENTS, MCBRAT_MAX_EVENTS_NAN, MCBRAT_WATCHDOG
   int legacyTies = 0;                   // MCBRAT_TEST_LEGACY_TIES (tests only)
   // mcbrat_frequency_distribution's device buffers, kept and grown with numLambda
   double *dFreqCdf = nullptr;
@@ -799,6 +799,7 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (const char *e = getenv("MCBRAT_TUNE_PHOTONS")) c->tuneTrialPhotons = strtoull(e, nullptr, 10);
   if (const char *e = getenv("MCBRAT_WATCHDOG")) c->watchdog = (unsigned)std::max(16ll, atoll(e));
   if (const char *e = getenv("MCBRAT_MAX_EVENTS")) c->maxEvents = (unsigned)std::max(16ll, atoll(e));
+  if (const char *e = getenv("MCBRAT_MAX_EVENTS_NAN")) c->maxEventsNaN = (unsigned)std::max(16ll, atoll(e));
   if (const char *e = getenv("MCBRAT_TEST_LEGACY_TIES")) c->legacyTies = atoi(e);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {

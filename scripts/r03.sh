@@ -77,6 +77,23 @@ step_soak() {  # the random differential tests with more seeds (SOAK seeds each,
   done
   return 0
 }
+step_profiles() {  # the measurement record of the shipped kernels: bench lines, rocprofv3 kernel stats, PMC passes (-> profiles/r03_*)
+  local P=$OUT/prof; mkdir -p $P
+  python bench.py --pipelined-extra > $P/bench_stepcloud.json 2> $P/bench_stepcloud.err; echo "bench step rc=$?"
+  python bench.py --workload landsatLike128 --steps 5 --warmup 1 > $P/bench_landsat.json 2> $P/bench_landsat.err; echo "bench landsat rc=$?"
+  python bench.py --workload homogLW20x16 --steps 5 --warmup 1 > $P/bench_lw.json 2> $P/bench_lw.err; echo "bench lw rc=$?"
+  python bench.py --workload radarLike128 --steps 3 --warmup 1 --no-cpu-baseline > $P/bench_radar.json 2> $P/bench_radar.err; echo "bench radar rc=$?"
+  python bench.py --block-walk 0 --no-cpu-baseline --no-secondary > $P/bench_stepcloud_facebyface.json 2> $P/bench_fbf.err; echo "bench fbf rc=$?"
+  BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-secondary --steps 5 > $P/bench_stepcloud_rccl1.json 2> $P/bench_rccl1.err; echo "bench rccl rc=$?"
+  ( cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_step -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --event-threshold 16 > $P/stats_step.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_landsat -- python3 $ROOT/bench.py --workload landsatLike128 --steps 5 --warmup 1 --no-cpu-baseline --event-threshold 20 > $P/stats_landsat.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_lw -- python3 $ROOT/bench.py --workload homogLW20x16 --steps 3 --warmup 1 --no-cpu-baseline > $P/stats_lw.log 2>&1 )
+  bash scripts/pmc_profile.sh step r03/prof/pmc_step --thr 16 > $P/pmc_step.log 2>&1
+  bash scripts/pmc_profile.sh landsat r03/prof/pmc_landsat --thr 20 > $P/pmc_landsat.log 2>&1
+  find $P -name "*kernel_stats.csv" | xargs -n1 head -3 | cut -c1-200
+  echo profiles done
+}
 step_ab() {  # A/B of libraries in ab/: scripts/r03.sh ab <case> <thr> lib1 lib2 ...  (case: step | landsat | radar)
   local case=$1 thr=$2; shift 2
   local log=$OUT/ab_${case}_$(ts).log

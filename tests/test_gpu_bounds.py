@@ -75,12 +75,14 @@ def test_soak_finds_end_with_the_original_tie_handling(M, which, seed, ties, mon
 @pytest.mark.timeout(120, method="thread")
 @pytest.mark.parametrize("walk,tuning", [("face by face", dict(privateTallies=0, layerSkip=0)), ("LDS face by face", dict(blockWalk=0)),
                                          ("block walk", dict(blockWalk=2))])
-def test_nan_table_entry_under_conservative_scattering_ends(M, walk, tuning):
+def test_nan_table_entry_under_conservative_scattering_ends(M, walk, tuning, monkeypatch):
     """computeInversePhaseFunction can leave a NaN in the table (one entry in 9001 for a 64-term HG
     series with g = 0.5).  A photon that draws it has a NaN direction and collides on in its cell; with omega0 = 1 its
     weight never falls, so neither roulette nor the reference's loop would ever end it.  Here it is dropped after
-    maxEventsNaN legs and counted; the energy it carried is the only energy missing."""
+    maxEventsNaN legs (2^20, about a second per photon; 4096 in this test) and counted; the energy it carried is the only
+    energy missing."""
     from oracle import oracle as O
+    monkeypatch.setenv("MCBRAT_MAX_EVENTS_NAN", "4096")
     leg = cases.hg_legendre(0.5, 64)
     assert np.isnan(O.inverse_table_legendre(leg, 9001)).any()  # (the premise: this table does hold a NaN)
     nx = nz = 8

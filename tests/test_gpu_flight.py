@@ -272,8 +272,14 @@ def test_random_fields_against_face_by_face_walk(M, seed):
         assert abs(b["means"][0] + b["means"][2] + (1.0 - case["albedo"]) * b["means"][1] - 1.0) < 4.0 / np.sqrt(n)
 
 
+# seed the 2000-seed soak of round 3 found: 871 (a photon with a NaN direction -- a NaN entry of the inverse table -- that had just
+# survived roulette for the fifth time under omega0 = 0.9993 was at full weight after 4690 legs and met the first, too tight,
+# version of the leg budget for such photons: every integrator's badPhotons must stay 0)
+LAYERING_SOAK_FINDS = (871,)
+
+
 @pytest.mark.timeout(120, method="thread")
-@pytest.mark.parametrize("seed", range(FUZZ))
+@pytest.mark.parametrize("seed", sorted(set(range(FUZZ)) | set(LAYERING_SOAK_FINDS)))
 def test_random_layerings_against_face_by_face_walk(M, seed):
     """Differential test on random LAYERINGS: every layer is, at random, vacuum, a haze of one extinction value, broken
     cloud over a clear or hazy background (so that cloud decks alternate with layers of one value inside the brick columns'
