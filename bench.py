@@ -353,7 +353,9 @@ def lw_bench(a, M, torch, dist, dev, rank, local_rank, world, rehearse):
         rng.nextPhotonId = (i * world + rank) * per_step
         run.resetMoments()
         counts = run.run(ppb, nb, rng, seed=1000 + i * world + rank)
-        kms = sum(it.lastTraceMs() for it in run.integrators)  # (of each wavelength's last call; see launches_per_step)
+        for it in run.integrators:  # (a step is synchronous: every wavelength's photons traced and folded into the moments)
+            it.synchronize()
+        kms = 0.0  # (the wavelengths' tracing kernels overlap: their durations are measured apart, below)
         launches[0] = int(sum((c // ppb) > 0 for c in counts) + sum((c % ppb) > 0 for c in counts))
         if dist is not None:
             dist.all_reduce(moments, op=dist.ReduceOp.SUM)
@@ -388,6 +390,8 @@ def lw_bench(a, M, torch, dist, dev, rank, local_rank, world, rehearse):
             run.bindMoments(0)
         # untimed: one step with every wavelength's photons in ONE call each: tracing-kernel time per step (HIP events around
         # each tracing kernel, summed over the 16 wavelengths) and, from the instrumented instantiation, the event counters
+        run.set_overlap(False)  # (kernel durations that describe the kernel: one launch at a time, the host waits for each)
+
         def one_call_per_wavelength(counters):
             for it in run.integrators:
                 it.enableCounters(counters)
@@ -416,6 +420,9 @@ def lw_bench(a, M, torch, dist, dev, rank, local_rank, world, rehearse):
                           "photons_per_step_per_gpu": per_step, "parallelism": "photon batches sharded over %d GPU(s)" % world,
                           "world_size": world, "photons_in_reduced_moments_last_step": reduced_photons,
                           "kernel_launches_per_step": launches[0], "setup_and_upload_s_once": t_setup,
+                          "wavelengths_overlap": "tracing kernels of consecutive wavelengths overlap on the GPU (each context asynchronous, "
+                                                 "finish chains ordered on the device by mcbrat_chain_after); roofline.kernel_ms_per_launch is "
+                                                 "measured apart with one launch at a time",
                           "emitted_flux_W_m2": flux, "event_threshold": run.first.eventThreshold(), "walk": walk,
                           "bad_photons": int(sum(it.badPhotons() for it in run.integrators)),
                           **({"rehearsal": "gloo, all ranks on cuda:0 -- not a measurement"} if rehearse else {})},
@@ -439,6 +446,7 @@ def lw_bench(a, M, torch, dist, dev, rank, local_rank, world, rehearse):
                 cb["calibration_source"] = rec["source"] + " (measured on the step cloud; applied to this workload as a proxy)"
             out["cpu_baseline"] = cb
             if world > 1:
+                run.set_overlap(True)
                 run.resetMoments(); rng.nextPhotonId = 5 * 10 ** 12
                 run.run(ppb, nb, rng, seed=5)
                 stats = driver.statistics(driver.unpack_moments(run.moments(), nx, ny, nz), solarFlux=flux)

@@ -194,6 +194,14 @@ int mcbrat_synchronize(mcbrat_ctx *ctx);
  * enqueued so far.  Neither blocks the host. */
 int mcbrat_stream_wait_done(mcbrat_ctx *ctx, void *hipStream);
 int mcbrat_wait_stream(mcbrat_ctx *ctx, void *hipStream);
+/* Several contexts that accumulate into ONE moment array (mcbrat_bind_moments with another context's
+ * mcbrat_moments_device_pointer: one context per wavelength of a spectrally integrated run, monteCarloDriver.f95:889-1085) must
+ * fold their batches one context after the other.  In synchronous mode the host does that by waiting for every call.  With
+ * mcbrat_set_async on each of them, mcbrat_chain_after(ctx, previous) orders the device instead: the finish kernels (and the
+ * reset) of ctx's NEXT call run after everything `previous` has enqueued so far, while the tracing kernels of the two contexts
+ * overlap -- the tail of one wavelength's launch is filled by the next wavelength's photons.  Results are bitwise those of
+ * synchronous calls in the same order.  Both contexts must live on the same device; `previous` must outlive the chained call. */
+int mcbrat_chain_after(mcbrat_ctx *ctx, mcbrat_ctx *previous);
 /* Tuning knobs (negative = leave unchanged): workgroups per CU (0 = occupancy query), number of
  * walking lanes below which a wave serves its waiting lanes (0 = choose by timing short trial
  * launches, the default), batches in flight per launch

@@ -67,6 +67,7 @@ SYMBOLS = {
     "mcbrat_synchronize": (C.c_int, [_vp]),
     "mcbrat_stream_wait_done": (C.c_int, [_vp, _vp]),
     "mcbrat_wait_stream": (C.c_int, [_vp, _vp]),
+    "mcbrat_chain_after": (C.c_int, [_vp, _vp]),
     "mcbrat_set_tuning": (C.c_int, [_vp] + [_i32] * 8),
     "mcbrat_set_walk_options": (C.c_int, [_vp, _i32, _i32]),
     "mcbrat_get_walk_mode": (C.c_int, [_vp]),

@@ -86,15 +86,19 @@ class SpectralRun:
     loop, Drivers/monteCarloDriver.f95:936).  The loop over (wavelength, batch) units (:889-1085) then only launches
     kernels.  The photons are split over wavelengths on the device (getFrequencyDistr, driver :438-449)."""
 
-    def __init__(self, M, domains, device=0, **parameters):
+    def __init__(self, M, domains, device=0, overlap=True, **parameters):
+        """overlap: the wavelengths' tracing kernels may overlap on the GPU (each integrator asynchronous, the finish chains
+        of consecutive calls ordered on the device by chainAfter): the tail of one wavelength's launch is filled by the next
+        wavelength's photons.  Bitwise the results of overlap=False (every call waited for by the host)."""
         if not domains:
             raise McbratError("SpectralRun: no wavelength domains")
+        self.overlap = bool(overlap)
         self.M, self.domains = M, list(domains)
         self.integrators = [M.new_Integrator(d, device=device) for d in self.domains]
         for it in self.integrators:
             it.specifyParameters(**parameters)
         self.first = self.integrators[0]
-        self._bound, self._bound_ptr = False, None
+        self._bound, self._bound_ptr, self._last = False, None, None
         self.streams, self.counts, self.cdf, self.totalFlux = None, None, None, 0.0
 
     def _bind(self):
@@ -104,8 +108,8 @@ class SpectralRun:
         ptr = self.first.momentsDevicePointer()
         if not self._bound or ptr != self._bound_ptr:
             for it in self.integrators:
-                it.setAsync(False)
                 it._shares_moments = len(self.integrators) > 1
+                it.setAsync(self.overlap and len(self.integrators) > 1, _chained=True)
             for it in self.integrators[1:]:
                 it.bindMoments(ptr)
             self._bound, self._bound_ptr = True, ptr
@@ -154,19 +158,34 @@ class SpectralRun:
         total = int(numPhotonsPerBatch) * int(numBatches)
         self.counts = np.asarray(counts, np.int64) if counts is not None else \
             device_frequency_distribution(self.first, self.cdf, total, seed)
+        last = self._last
         for dom, it, ps, n in zip(self.domains, self.integrators, self.streams, self.counts):
             full, rest = divmod(int(n), int(numPhotonsPerBatch))
             ps.currentPhoton = 1
-            if full:
-                it.computeRadiativeTransfer(dom, randomNumbers, ps, int(numPhotonsPerBatch), full)
-            if rest:
-                it.computeRadiativeTransfer(dom, randomNumbers, ps, rest, 1)
+            for ppb, nb in ((int(numPhotonsPerBatch), full), (rest, 1 if rest else 0)):
+                if nb:
+                    if self.overlap and last is not None and last is not it:
+                        it.chainAfter(last)  # (the device orders the two contexts' finish kernels; the host does not wait)
+                    it.computeRadiativeTransfer(dom, randomNumbers, ps, ppb, nb)
+                    last = it
+        self._last = last
         return self.counts
+
+    def set_overlap(self, overlap):
+        """Switch between overlapping and host-serialised wavelengths (takes effect with the next run)."""
+        for it in self.integrators:
+            it.synchronize()
+        self.overlap = bool(overlap)
+        self._bound = False
+        self._bind()
 
     def resetMoments(self):
         self._bind()
+        for it in self.integrators:  # (everything enqueued so far has written the array that is about to be cleared)
+            it.synchronize()
         self.first.resetMoments()
         self.first.synchronize()
+        self._last = self.first
 
     def moments(self):
         for it in self.integrators:

@@ -38,6 +38,8 @@ struct mcbrat_ctx {
   hipEvent_t lastDone = nullptr;   // evDone of the most recent call: the next finish chain waits for it
   hipEvent_t evExternal = nullptr; // recorded on a caller's stream by mcbrat_wait_stream
   bool externalPending = false;
+  mcbrat_ctx *chainAfter = nullptr; // mcbrat_chain_after: the context whose finish chain this context's next one follows
+  hipEvent_t chainSnapshot = nullptr; // ... and what it had enqueued when the chain was asked for (its lastDone then)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing, eventPool;  // asynchronous mode: kernel brackets not yet read
   Lane &L() { return lane[cur]; }
   std::string err;
@@ -197,6 +199,7 @@ int sync_all(mcbrat_ctx *c) {
     c->lastTraceMs = total;
   }
   if (c->hBad) c->lastCounters.badPhotons = (int64_t)*c->hBad;
+  if (c->asyncOn) c->nextLane = 0;  // (everything has finished: the rotation may start at the first stream again)
   return 0;
 }
 
@@ -1031,6 +1034,10 @@ int mcbrat_reset_moments(mcbrat_ctx *c) {
   if (ensure_moments(c)) return 1;
   // c->cur is the lane of the latest call: its stream already orders this after every earlier finish chain
   if (c->externalPending) { HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->evExternal, 0)); c->externalPending = false; }
+  if (c->chainAfter) {
+    if (c->chainSnapshot) HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->chainSnapshot, 0));
+    c->chainAfter = nullptr; c->chainSnapshot = nullptr;
+  }
   HIP_OK(c, hipMemsetAsync(c->dMoments, 0, sizeof(double) * (8 + 2 * (size_t)moments_len(c)), c->L().stream));
   // stream-ordered before whatever the context enqueues next; readers synchronise (get_moments, report_results)
   HIP_OK(c, hipEventRecord(c->L().evDone, c->L().stream));
@@ -1157,9 +1164,9 @@ int mcbrat_set_async(mcbrat_ctx *c, int32_t enable) {
   if (sync_all(c)) return 1;
   c->asyncOn = enable != 0;
   c->cur = 0; c->nextLane = 0;
-  if (c->asyncOn)
-    for (int i = 0; i < mcbrat_ctx::kLanes; ++i)
-      if (init_lane(c, i)) return 1;
+  // (streams are created when a call first rotates onto them, and the rotation starts again after every synchronisation:
+  // a caller that issues two calls between synchronisations -- a wavelength of a spectrally integrated run, of which a
+  // run keeps sixteen contexts alive -- holds two streams and two sets of tally slabs, not four)
   return 0;
 }
 
@@ -1181,6 +1188,15 @@ int mcbrat_wait_stream(mcbrat_ctx *c, void *stream) {
   (void)hipSetDevice(c->device);
   HIP_OK(c, hipEventRecord(c->evExternal, (hipStream_t)stream));
   c->externalPending = true;
+  return 0;
+}
+
+int mcbrat_chain_after(mcbrat_ctx *c, mcbrat_ctx *previous) {
+  if (!c || !previous) return 1;
+  if (c == previous) return fail(c, "chain_after: a context follows its own calls by itself.");
+  if (c->device != previous->device) return fail(c, "chain_after: the two contexts are on different devices.");
+  c->chainAfter = previous;
+  c->chainSnapshot = previous->lastDone;  // (an event of `previous`, alive as long as it is; waited for before this context's next finish kernels)
   return 0;
 }
 
@@ -1370,6 +1386,10 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     // whatever a caller's stream did to that array (mcbrat_wait_stream)
     if (c->lastDone && c->lastDone != c->L().evDone) HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->lastDone, 0));
     if (c->externalPending) { HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->evExternal, 0)); c->externalPending = false; }
+    if (c->chainAfter) {  // contexts that share one moment array (one per wavelength): this finish chain after the other context's
+      if (c->chainSnapshot) HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->chainSnapshot, 0));
+      c->chainAfter = nullptr; c->chainSnapshot = nullptr;
+    }
     FinishParams f;
     f.nx = c->nx; f.ny = c->ny; f.nz = c->nz; f.nBatches = nb; f.xyRegular = c->xyRegular; f.nDir = c->nDir; f.nc = c->nc; f.limitContrib = c->limitContrib;
     f.ppb = p.ppb; f.total = p.total; f.slabStride = slabStride;

@@ -225,12 +225,17 @@ class Integrator:
     def eventThreshold(self):
         return int(self._lib.mcbrat_get_event_threshold(self._ctx))
 
-    def setAsync(self, enable=True):
+    def setAsync(self, enable=True, _chained=False):
         """Let consecutive computeRadiativeTransfer / resetMoments calls overlap on the GPU (include/mcbrat.h)."""
-        if enable and getattr(self, "_shares_moments", False):
+        if enable and getattr(self, "_shares_moments", False) and not _chained:
             raise McbratError("setAsync: this integrator accumulates into a moment array it shares with other integrators "
-                              "(SpectralRun); their finish kernels are only ordered in synchronous mode")
+                              "(SpectralRun); their finish kernels are only ordered in synchronous mode, or by chainAfter")
         self._check(self._lib.mcbrat_set_async(self._ctx, int(bool(enable))))
+
+    def chainAfter(self, previous):
+        """The finish kernels of this integrator's next call follow everything `previous` (an integrator that accumulates
+        into the same moment array) has enqueued so far (mcbrat_chain_after)."""
+        self._check(self._lib.mcbrat_chain_after(self._ctx, previous._ctx))
 
     def synchronize(self):
         self._check(self._lib.mcbrat_synchronize(self._ctx))

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 GPU_DEFAULT_TIMEOUT = 300  # seconds; tests that need less or more carry their own @pytest.mark.timeout
 
 
+try:  # PyTorch brings a HIP runtime of its own (a second copy in this process, beside the one the product links).  It finds the
+    # GPU when it is loaded before the product has initialised the device, and may not when loaded after (seen on the GPU box:
+    # "No HIP GPUs are available" where tests/test_gpu_spectral.py, the one GPU test that hands a torch tensor to the library,
+    # ran without the CPU test modules that import torch at collection).  Loaded here, the order is the same in every session.
+    import torch  # noqa: F401
+except Exception:  # (a session without PyTorch still runs everything that does not need it)
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than a few seconds on CPU")

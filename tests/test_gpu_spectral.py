@@ -110,6 +110,32 @@ def test_resident_thermal_spectrum_matches_the_oracle_loop(M):
     run.finalize()
 
 
+def test_overlapping_wavelengths_are_bitwise_the_host_serialised_run(M):
+    """SpectralRun(overlap=True): every wavelength's integrator asynchronous, the finish chains of consecutive calls ordered on
+    the device (mcbrat_chain_after), tracing kernels of different wavelengths overlapping -- against overlap=False, where the
+    host waits for every call: the same photons folded in the same order, so the moment arrays must be bitwise equal; twice
+    in a row (a second run re-uses lanes and events), with full batches and a rest batch per wavelength."""
+    from mcbrat3d_amd import broadband
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    lambdas = [8.0, 9.5, 10.5, 12.0]
+    cs = [cases.homog_lw(n=20, lam=lam, ext=4.0 + lam / 4.0, ssa=0.6) for lam in lambdas]
+    out = {}
+    for overlap in (False, True):
+        run = broadband.SpectralRun(M, [cases.product_domain(c) for c in cs], overlap=overlap, minInverseTableSize=9001)
+        run.prepare_thermal(300.0)
+        res = []
+        for rep in range(2):
+            run.resetMoments()
+            counts = run.run(7000, 9, new_RandomNumberSequence(SEED + rep), seed=11 + rep)
+            res.append((counts.copy(), run.moments().copy()))
+        assert sum(it.badPhotons() for it in run.integrators) == 0
+        run.finalize()
+        out[overlap] = res
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a[0], b[0]) and a[1][0] == 63000
+        assert np.array_equal(a[1], b[1])
+
+
 def test_resident_solar_spectrum_matches_the_oracle_loop(M):
     """Solar broadband: solar_Weighting (emissionAndBroadBandWeights.f95:149-217) over four wavelength domains of the
     step cloud whose extinction and single-scattering albedo change with wavelength."""
