@@ -27,7 +27,7 @@ module mcbrat_hip_integrator
             resetMoments, getMoments, momentsLength, lastMessage, &
             inverseTableLegendre, lastTraceMilliseconds, setAsynchronous, synchronize, &
             specifyIntensity, setForwardTable, reportIntensity, forwardTableLegendre, &
-            setSurfaceDescription, setWalkOptions, getFrequencyDistr, shareMoments, numBadPhotons
+            setSurfaceDescription, setWalkOptions, getFrequencyDistr, shareMoments, chainAfter, numBadPhotons
 
   interface
     function mcbrat_create(device) bind(C, name="mcbrat_create") result(ctx)
@@ -174,6 +174,11 @@ module mcbrat_hip_integrator
       import :: c_ptr, c_float
       type(c_ptr), value :: ctx
       real(c_float) :: ms
+    end function
+    function mcbrat_chain_after(ctx, previous) bind(C, name="mcbrat_chain_after") result(rc)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx, previous
+      integer(c_int) :: rc
     end function
     function mcbrat_get_counters(ctx, counters) bind(C, name="mcbrat_get_counters") result(rc)
       import :: c_ptr, c_int, c_int64_t
@@ -463,6 +468,13 @@ contains
     integer, intent(out) :: ierr
     ierr = mcbrat_bind_moments(this%ctx, mcbrat_moments_device_pointer(first%ctx))
   end subroutine shareMoments
+  ! ... and, with both integrators asynchronous (setAsynchronous), `this` folds the batches of its NEXT call after everything
+  ! `previous` has enqueued so far, while the two integrators' tracing kernels overlap (mcbrat_chain_after, include/mcbrat.h)
+  subroutine chainAfter(this, previous, ierr)
+    type(integrator), intent(inout) :: this, previous
+    integer, intent(out) :: ierr
+    ierr = mcbrat_chain_after(this%ctx, previous%ctx)
+  end subroutine chainAfter
   real function lastTraceMilliseconds(this)
     type(integrator), intent(in) :: this
     lastTraceMilliseconds = mcbrat_last_trace_ms(this%ctx)
