@@ -92,6 +92,8 @@ def lib():
                               "(there is no CPU fallback)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("MCBRAT_LIB_OLD") and not hasattr(L, name):
+                continue  # (A/B runs against a library built from an earlier round's sources: MCBRAT_LIB=... MCBRAT_LIB_OLD=1)
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

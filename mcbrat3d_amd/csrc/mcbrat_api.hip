@@ -199,7 +199,6 @@ int sync_all(mcbrat_ctx *c) {
     c->lastTraceMs = total;
   }
   if (c->hBad) c->lastCounters.badPhotons = (int64_t)*c->hBad;
-  if (c->asyncOn) c->nextLane = 0;  // (everything has finished: the rotation may start at the first stream again)
   return 0;
 }
 
@@ -493,7 +492,7 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.crossThreshold = std::max(1, std::min(64, c->crossThreshold));
   p.jumpThreshold = std::max(1, std::min(64, c->jumpThreshold));
   p.bad = c->dBad;
-  p.maxEvents = c->maxEvents; p.maxEventsNaN = c->maxEventsNaN; p.watchdog = c->watchdog;
+  p.maxEvents = c->maxEvents; p.maxEventsNaN = std::min(c->maxEventsNaN, c->maxEvents); p.watchdog = c->watchdog;  // (the kernels test the smaller one first)
   p.legacyTies = c->legacyTies;
   {
     // no view ray is longer than the domain's height over the smallest |mu| of the views (and a hair for rounding)
@@ -715,7 +714,10 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   if (block_walk_applies(c, L))
     return launch_block_s<768, true, false, false, 2>(c, p, block_lds_layout(c->nx, c->ny, c->nz, c->nc, (size_t)p.slabStride, c->nBlocks, (size_t)c->tblTotalFloats).total, nBatches);
   if (debug) return launch_trace_e<256, false, 0, false, true, false, false, 0>(c, p, L.lds, nBatches);
-  return launch_trace_e<256, false, 0, false, false, false, false, 3>(c, p, L.lds, nBatches);
+  if (!(p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0)) return fail(c, "development build: only the bench workloads' kernels exist");
+  if (p.xyRegularWalk && !p.zRegularWalk) return launch_trace_e<256, false, 0, false, false, false, false, 3>(c, p, L.lds, nBatches);
+  if (!p.xyRegularWalk && !p.zRegularWalk) return launch_trace_e<256, false, 0, false, false, false, false, 1>(c, p, L.lds, nBatches);  // (the 128x128x64 bench fields)
+  return fail(c, "development build: only the bench workloads' kernels exist");
 #else
   if (block_walk_applies(c, L)) return launch_block(c, p, L, debug, nBatches);
   // small domains (grid, tables and tallies in LDS): LDS holds two workgroups per CU, and two workgroups of 12 waves
@@ -1164,9 +1166,9 @@ int mcbrat_set_async(mcbrat_ctx *c, int32_t enable) {
   if (sync_all(c)) return 1;
   c->asyncOn = enable != 0;
   c->cur = 0; c->nextLane = 0;
-  // (streams are created when a call first rotates onto them, and the rotation starts again after every synchronisation:
-  // a caller that issues two calls between synchronisations -- a wavelength of a spectrally integrated run, of which a
-  // run keeps sixteen contexts alive -- holds two streams and two sets of tally slabs, not four)
+  if (c->asyncOn)  // (every stream now: the first asynchronous call sizes all of them at once -- allocation synchronises the device)
+    for (int i = 0; i < mcbrat_ctx::kLanes; ++i)
+      if (init_lane(c, i)) return 1;
   return 0;
 }
 

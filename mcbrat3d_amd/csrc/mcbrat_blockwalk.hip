@@ -194,7 +194,9 @@ trace_block_kernel(const DevParams p) {
   auto inRange = [](int j, unsigned r) { return min(max(j, (int)(r & 0xffffu)), (int)(r >> 16) - 1); };
   // TEST ONLY (DevParams::legacyTies): the tie handling from before the three fixes the soak runs led to, to show that the
   // bounds below end the kernel without them (tests/test_gpu_edge_cases.py).  Wave-uniform, read in the rare phases only.
-  const bool legacyNoClamp = (p.legacyTies & 1) != 0, legacyMoveNaN = (p.legacyTies & 2) != 0, legacyKeepSpans = (p.legacyTies & 4) != 0;
+  // (compiled into the instrumented instantiation only -- the one mcbrat_trace_fates runs: the production kernels carry none of it)
+  const bool legacyNoClamp = DEBUG && (p.legacyTies & 1) != 0, legacyMoveNaN = DEBUG && (p.legacyTies & 2) != 0,
+             legacyKeepSpans = DEBUG && (p.legacyTies & 4) != 0;
   auto inRangeX = [&](int j, unsigned r) { return legacyNoClamp ? j : inRange(j, r); };  // clamp of a block crossing
   // Distances along the leg to the faces of the block that holds cell (ix, iy, iz); its extinction.
   auto enterBlock = [&](int ix, int iy, int iz) {
@@ -215,11 +217,20 @@ trace_block_kernel(const DevParams p) {
 
   // Watchdog (wave-uniform, scalar; see trace_kernel): loop iterations in which no lane of the wave started a leg, took a
   // new photon or was refused one.  When it fires every lane that is not dead is dropped and counted (DevParams::bad).
-  unsigned sinceProgress = 0;
+  // Why the loop ends.  In one iteration a lane in BW_MOVE always leaves that state (collision, block face, exit or
+  // drop) and a lane in BW_COLLIDE dies or starts a leg; lanes waiting for a crossing or an exit are served as soon as
+  // fewer than eventThreshold lanes collide.  So every iteration starts a leg, serves a crossing or ends a photon, and
+  // two counters bound the lot: legs per photon (maxEvents) and block crossings per leg (the `watchdog` figure, here a
+  // per-lane count -- the kernel has VGPRs to spare and no SGPR).  Neither costs the iteration anything: the first is
+  // one compare where a leg starts, the second lives in the crossing's own branch.
+  unsigned nCrossLeg = 0;
+  unsigned nBadLane = 0;  // photons this lane dropped at a loop bound; added to *p.bad when the kernel ends
+  const unsigned maxEvents = DEBUG ? p.maxEvents : kMaxEvents, maxEventsNaN = DEBUG ? p.maxEventsNaN : kMaxEventsNaN,
+                 watchdog = DEBUG ? p.watchdog : kWatchdog;
 #define MCBRAT_BW_DROP() do { \
     if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{3, 0, 0, 0, nScat, nLegs, w}; \
     state = BW_DEAD; \
-    atomicAdd(p.bad, 1ull); \
+    nBadLane++;  /* (added to *p.bad when the kernel ends: no atomic, no pointer in the loop) */ \
   } while (0)
 #ifdef MCBRAT_STAMPS  // development aid (-DMCBRAT_STAMPS): wave cycles per section of the loop, reported with the event counters
   __shared__ unsigned long long s_tprev[BLOCK / 64], s_stamp[BLOCK / 64][9];
@@ -243,6 +254,7 @@ trace_block_kernel(const DevParams p) {
     for (;;) {
       bool needLeg = false;
       int ix = 0, iy = 0, iz = 0;  // cell of a lane that starts a leg in this iteration
+
       // Rare kinds of work -- exits, launches, block crossings -- wait until enough lanes ask for them, or until the
       // wave has little else to do.  Exits come first and launches right after them: under a black surface every exit
       // frees its lane, so the lanes that have just left are refilled in the same iteration instead of queueing again.
@@ -532,14 +544,11 @@ trace_block_kernel(const DevParams p) {
       }
       STAMP(4);
       // ---- start the next leg: tau, 1/direction, the block the leg starts in ----
-      sinceProgress = (__ballot(needLeg) != 0ull || want != 0ull) ? 0u : sinceProgress + 1u;
-      if (sinceProgress > p.watchdog) {  // (wave-uniform; never in a run whose every lane makes progress)
-        if (state != BW_DEAD) MCBRAT_BW_DROP();
-        sinceProgress = 0u;
-      }
       // (a photon is allowed maxEvents legs; one with a NaN direction -- see the collision above -- maxEventsNaN: where
       // omega0 = 1 its weight never falls and neither the reference nor the roulette would ever end it)
-      if (needLeg && event >= ((dz == dz || w < 1.0f) ? p.maxEvents : p.maxEventsNaN)) { needLeg = false; MCBRAT_BW_DROP(); }
+      if (needLeg && event >= maxEventsNaN) {  // (one compare on the hot path: maxEventsNaN <= maxEvents; the rule itself in the rare branch)
+        if (event >= maxEvents || !(dz == dz || w < 1.0f)) { needLeg = false; MCBRAT_BW_DROP(); }
+      }
       if (needLeg) {
         event++;
         nLegs++;
@@ -563,6 +572,7 @@ trace_block_kernel(const DevParams p) {
         ivy = (!NOY && fabsf(dy) >= 2.0f * FLT_MIN) ? rcp_fast(dy) : 0.0f;
         ivz = fabsf(dz) >= 2.0f * FLT_MIN ? rcp_fast(dz) : 0.0f;
         spans = 0;  // (the leg starts inside the domain: its origin was folded where it was located)
+        nCrossLeg = 0u;
         enterBlock(ix, iy, iz);
         state = BW_MOVE;
       }
@@ -601,6 +611,7 @@ trace_block_kernel(const DevParams p) {
         if (!legacyKeepSpans) spans = 0;
         enterBlock(jx, jy, jz);
         state = BW_MOVE;
+        if (++nCrossLeg > watchdog) MCBRAT_BW_DROP();  // (a leg that has crossed 2^20 blocks is going round in circles)
       }
       STAMP(1);
       // wave-uniform exit: nothing alive and every lane has already been refused a new photon
@@ -655,6 +666,7 @@ trace_block_kernel(const DevParams p) {
     __syncthreads();
   }
 
+  if (nBadLane != 0u) atomicAdd(p.bad, (unsigned long long)nBadLane);
 #ifdef MCBRAT_STAMPS
   if (DEBUG && p.counters && lane == 0) for (int i = 0; i < 9; i++) atomicAdd(p.counters + 16 + i, s_stamp[threadIdx.x >> 6][i]);
 #endif

@@ -11,6 +11,13 @@ constexpr int kWave = 64;                     // CDNA wavefront
 constexpr double kTallyScale = 4294967296.0;  // tallies are signed 64-bit fixed point, 2^-32 resolution
 constexpr double kTallyInv = 1.0 / 4294967296.0;
 
+// Loop bounds of the production kernels -- compile-time constants there: as kernel parameters they
+// lived in scalar registers across the whole loop and cost the step cloud 3 % through spilled SGPRs.  The instrumented
+// instantiations (mcbrat_trace_fates, counters) take them from DevParams, so that tests can reach a bound quickly.
+constexpr unsigned kMaxEvents = 1u << 24;     // legs per photon
+constexpr unsigned kMaxEventsNaN = 1u << 20;  // legs of a photon with a NaN direction that is still at full weight
+constexpr unsigned kWatchdog = 1u << 20;      // trace_kernel: event phases of a wave in which none of its lanes makes progress; block walk: block crossings of one leg
+
 // States of a lane in the tracing loop.
 // ST_ENTER: a lane on the layer-skipping walk has reached a layer whose extinction varies from cell to cell and
 // waits for the event phase to bring its x/y state up to date.
@@ -119,12 +126,12 @@ struct DevParams {
   // here find cells from positions in places (block walk, clear-air flight, layer skipping), keep face distances in float,
   // and a table may hand out a NaN (section 8) -- so every loop carries a bound of its own instead of an argument about
   // rounding: a photon that exceeds one is dropped and counted in *bad (fate 3), as the reference counts nBad.
-  unsigned long long *bad;        // photons (and radiance rays) dropped by a bound; host-visible
-  unsigned maxEvents;             // legs per photon
-  unsigned maxEventsNaN;          // legs a photon may go on with a direction that is NaN
-  unsigned watchdog;              // loop iterations of a wave in which none of its lanes started a leg, took a photon or was refused one
+  unsigned long long *bad;        // photons (and radiance rays) dropped by a bound (counted per lane, one atomic per lane that dropped any at the kernel's end)
+  unsigned maxEvents;             // instrumented instantiations only (production: kMaxEvents ...): legs per photon
+  unsigned maxEventsNaN;          // ... legs a photon at full weight may go on with a direction that is NaN (<= maxEvents)
+  unsigned watchdog;              // ... trace_kernel: event phases of a wave in which no lane started a leg, took a photon or was refused one; block walk: block crossings of one leg
   float rayMaxLen;                // radiance: no view ray is longer than (zMax - z0) / min |mu| (geometry)
-  int legacyTies;                 // TEST ONLY (MCBRAT_TEST_LEGACY_TIES): bit 0 / 1 / 2 re-enable the block walk's tie handling from before the
+  int legacyTies;                 // TEST ONLY (MCBRAT_TEST_LEGACY_TIES; instrumented instantiation only): bit 0 / 1 / 2 re-enable the block walk's tie handling from before the
                                   // fixes of soak seeds 168 / 71 / 763 (no clamp to the block left / move along a NaN / span bits outlive the fold)
   unsigned ldsBytes;              // dynamic LDS of the launch (-DMCBRAT_POISON fills it before the kernel initialises its part)
   // debug / measurement

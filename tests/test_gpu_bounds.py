@@ -51,7 +51,7 @@ LEGACY = [("box", 168, 1),      # cell look-ups of a block crossing not clamped 
 @pytest.mark.parametrize("which,seed,ties", LEGACY)
 def test_soak_finds_end_with_the_original_tie_handling(M, which, seed, ties, monkeypatch):
     """Seeds 168, 71 and 763 hung the block walk before their fixes.  With the pre-fix handling switched back on the
-    kernel must still END: the stuck photon is dropped by the watchdog (or the leg budget) and counted, everybody
+    kernel must still END: the stuck photon is dropped by the bound on a leg's block crossings (or the leg budget) and counted, everybody
     else's history is what the fixed kernel gives."""
     case, mu0, phi0, rr = random_box_case(seed) if which == "box" else random_oracle_case(seed)
     n = 20000 if which == "box" else 15000
@@ -59,11 +59,13 @@ def test_soak_finds_end_with_the_original_tie_handling(M, which, seed, ties, mon
     good = _run(M, case, mu0, phi0, rr, n, tables, blockWalk=2)
     assert good[2] == 0 and good[3] == 0
     monkeypatch.setenv("MCBRAT_TEST_LEGACY_TIES", str(ties))  # read when the context is created
-    monkeypatch.setenv("MCBRAT_WATCHDOG", "50000")             # (the default, 2^20 loop iterations, takes about a second to fire)
+    monkeypatch.setenv("MCBRAT_WATCHDOG", "50000")             # (the default, 2^20 block crossings of one leg, takes about a second to reach)
     monkeypatch.setenv("MCBRAT_MAX_EVENTS", "200000")          # (the default, 2^24 legs, takes many seconds for a lone photon to reach)
     old = _run(M, case, mu0, phi0, rr, n, tables, blockWalk=2)
     dropped = old[0]["fate"] == 3
-    assert dropped.sum() == old[2] and old[2] == old[3], (dropped.sum(), old[2], old[3])  # the same photons in both calls
+    # (the switch is compiled into the instrumented instantiation only -- the one traceFates runs; the production kernel
+    # of the second call ignores it and drops nothing)
+    assert dropped.sum() == old[2] and old[3] == 0, (dropped.sum(), old[2], old[3])
     assert old[2] <= 8, old[2]
     keep = ~dropped
     same = (old[0]["fate"][keep] == good[0]["fate"][keep]) & (old[0]["nScatter"][keep] == good[0]["nScatter"][keep])
@@ -79,8 +81,8 @@ def test_nan_table_entry_under_conservative_scattering_ends(M, walk, tuning, mon
     """computeInversePhaseFunction can leave a NaN in the table (one entry in 9001 for a 64-term HG
     series with g = 0.5).  A photon that draws it has a NaN direction and collides on in its cell; with omega0 = 1 its
     weight never falls, so neither roulette nor the reference's loop would ever end it.  Here it is dropped after
-    maxEventsNaN legs (2^20, about a second per photon; 4096 in this test) and counted; the energy it carried is the only
-    energy missing."""
+    2^20 legs -- about a second per photon, the production kernels' constant; 4096 in the instrumented instantiation of this
+    test (MCBRAT_MAX_EVENTS_NAN) -- and counted; the energy it carried is the only energy missing."""
     from oracle import oracle as O
     monkeypatch.setenv("MCBRAT_MAX_EVENTS_NAN", "4096")
     leg = cases.hg_legendre(0.5, 64)
@@ -100,8 +102,9 @@ def test_nan_table_entry_under_conservative_scattering_ends(M, walk, tuning, mon
 @pytest.mark.timeout(120, method="thread")
 @pytest.mark.parametrize("block_walk", [0, 1])
 def test_leg_budget(M, block_walk, monkeypatch):
-    """MCBRAT_MAX_EVENTS (default 2^24 legs per photon) set to 16 on the conservative step cloud: the photons that need
-    more legs are dropped with fate 3 and counted; the others are untouched."""
+    """The leg budget (2^24 legs per photon: a compile-time constant of the production kernels; the instrumented instantiation
+    takes it from MCBRAT_MAX_EVENTS) set to 16 on the conservative step cloud: the photons that need more legs are dropped
+    with fate 3 and counted; the others are untouched, and so is the production run of the same photons."""
     case = cases.step_cloud(ssa=1.0)
     n = 20000
     full = _run(M, case, 1.0, 0.0, True, n, 10001, blockWalk=block_walk)
@@ -111,6 +114,6 @@ def test_leg_budget(M, block_walk, monkeypatch):
     long_ones = full[0]["nEvents"] > 16
     assert long_ones.sum() > 100
     assert np.array_equal(cut[0]["fate"] == 3, long_ones)
-    assert cut[2] == cut[3] == int(long_ones.sum())
+    assert cut[2] == int(long_ones.sum()) and cut[3] == 0
     short = ~long_ones
     assert np.array_equal(cut[0]["fate"][short], full[0]["fate"][short]) and np.array_equal(cut[0]["nScatter"][short], full[0]["nScatter"][short])
