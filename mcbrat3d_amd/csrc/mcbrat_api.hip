@@ -136,7 +136,8 @@ struct mcbrat_ctx {
                                // ranges (MCBRAT_LAYER_SKIP / mcbrat_set_walk_options: 0 off, 1 both, 2 the layers only)
   // loop bounds of the kernels (DevParams::bad ...) and the count of what they dropped
   unsigned long long *dBad = nullptr;   // device: photons / rays dropped since the context was created
-  unsigned long long *hBad = nullptr;   // pinned host copy, refreshed after every launch
+  unsigned long long *hBad = nullptr;   // pinned host copy, written by the last finish kernel of every call (hBadDev: the same word as the device sees it)
+  unsigned long long *hBadDev = nullptr;
   unsigned maxEvents = 1u << 24, maxEventsNaN = 1u << 20, watchdog = 1u << 20;  // MCBRAT_MAX_EVENTS, MCBRAT_MAX_EVENTS_NAN, MCBRAT_WATCHDOG
   int legacyTies = 0;                   // MCBRAT_TEST_LEGACY_TIES (tests only)
   // mcbrat_frequency_distribution's device buffers, kept and grown with numLambda
@@ -816,7 +817,8 @@ mcbrat_ctx *mcbrat_create(int device) {
       dev_malloc((void **)&c->dBad, sizeof(unsigned long long)) != hipSuccess ||
       hipMemsetAsync(c->dBad, 0, sizeof(unsigned long long), c->lane[0].stream) != hipSuccess ||
       hipStreamSynchronize(c->lane[0].stream) != hipSuccess ||
-      hipHostMalloc((void **)&c->hBad, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void **)&c->hBad, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&c->hBadDev, c->hBad, 0) != hipSuccess) {
     mcbrat_destroy(c);
     return nullptr;
   }
@@ -1338,7 +1340,7 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     if (L.slabCapacity < needSlab) {
       if (L.dSlabs) (void)hipFree(L.dSlabs);
       L.dSlabs = nullptr; L.slabCapacity = 0;
-      HIP_OK(c, dev_malloc((void **)&L.dSlabs, sizeof(long long) * needSlab));
+      HIP_OK(c, dev_malloc((void **)&L.dSlabs, sizeof(long long) * (needSlab + 1)));  // (+1: the launch's photon cursor sits behind the slabs in use, zeroed with them)
       L.slabCapacity = needSlab;
     }
     if (L.colCapacity < needCol) {
@@ -1375,8 +1377,8 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     const int nb = std::min<int>((int)inFlight, nBatches - b0);
     p.total = (unsigned long long)ppb * (unsigned long long)nb;
     p.firstPhoton = firstPhotonId + (unsigned long long)b0 * (unsigned long long)ppb;
-    HIP_OK(c, hipMemsetAsync(c->L().dSlabs, 0, sizeof(long long) * slabStride * nb, c->L().stream));  // zero tallies :248-252
-    HIP_OK(c, hipMemsetAsync(c->L().dCounter, 0, sizeof(unsigned long long), c->L().stream));
+    HIP_OK(c, hipMemsetAsync(c->L().dSlabs, 0, sizeof(long long) * (slabStride * nb + 1), c->L().stream));  // zero tallies :248-252, and the cursor
+    p.counter = reinterpret_cast<unsigned long long *>(c->L().dSlabs + slabStride * nb);
     std::pair<hipEvent_t, hipEvent_t> bracket(c->L().ev0, c->L().ev1);
     if (async && event_pair(c, bracket)) return 1;
     HIP_OK(c, hipEventRecord(bracket.first, c->L().stream));
@@ -1397,17 +1399,19 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     f.ppb = p.ppb; f.total = p.total; f.slabStride = slabStride;
     f.slabs = c->L().dSlabs; f.relArea = c->dRelArea; f.ze = c->dEdges + (c->nx + 1) + (c->ny + 1);
     f.colVals = c->L().dColVals; f.scalVals = c->L().dScalVals; f.moments = c->dMoments; f.last = c->dLast;
-    hipLaunchKernelGGL(finish_columns, dim3((unsigned)((ncol * (size_t)nb + 255) / 256)), dim3(256), 0, c->L().stream, f);
-    hipLaunchKernelGGL(finish_column_moments, dim3((unsigned)((3 * ncol + 255) / 256)), dim3(256), 0, c->L().stream, f);
-    hipLaunchKernelGGL(finish_volume, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, c->L().stream, f);
+    f.bad = c->dBad; f.badHost = c->hBadDev;
+    f.gatherColumns = (unsigned)((ncol * (size_t)nb + kFinishBlock - 1) / kFinishBlock);
+    f.gatherVolume = (unsigned)((nvox + kVolVox - 1) / kVolVox);
+    f.gatherReduce = (unsigned)(3 + c->nz) * (unsigned)nb;
+    f.gatherIntensity = (unsigned)((ncol * (size_t)c->nDir + kFinishBlock - 1) / kFinishBlock);
+    f.foldColumns = (unsigned)((3 * ncol + kFinishBlock - 1) / kFinishBlock);
+    f.foldScalars = (unsigned)((3 + c->nz + kFinishBlock - 1) / kFinishBlock);
     if (c->nDir > 0 && c->limitContrib)
       hipLaunchKernelGGL(finish_excess, dim3(c->nDir, nb), dim3(256), 0, c->L().stream, f);
-    if (c->nDir > 0)
-      hipLaunchKernelGGL(finish_intensity, dim3((unsigned)((ncol * (size_t)c->nDir + 255) / 256)), dim3(256), 0, c->L().stream, f);
-    hipLaunchKernelGGL(finish_reduce, dim3(3 + c->nz, nb), dim3(256), 0, c->L().stream, f);
-    hipLaunchKernelGGL(finish_scalars, dim3((unsigned)((3 + c->nz + 255) / 256)), dim3(256), 0, c->L().stream, f);
+    hipLaunchKernelGGL(finish_gather, dim3(f.gatherColumns + f.gatherVolume + f.gatherReduce + f.gatherIntensity), dim3(kFinishBlock), 0,
+                       c->L().stream, f);
+    hipLaunchKernelGGL(finish_fold, dim3(f.foldColumns + f.foldScalars), dim3(kFinishBlock), 0, c->L().stream, f);  // (also hands the dropped-photon count to the host)
     HIP_OK(c, hipGetLastError());
-    HIP_OK(c, hipMemcpyAsync(c->hBad, c->dBad, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->L().stream));
     HIP_OK(c, hipEventRecord(c->L().evDone, c->L().stream));
     c->lastDone = c->L().evDone;
     if (async) continue;

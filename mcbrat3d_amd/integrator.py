@@ -66,6 +66,7 @@ class Integrator:
         self.zetaMin = defaultZetaMin
         self.limitIntensityContributions = False
         self.maxIntensityContribution = float(np.finfo(np.float32).max)
+        self._param_token = None
         self._intensity_token = None
         self._domain_token = None
         self._source_token = None
@@ -184,8 +185,16 @@ class Integrator:
             self.useRussianRoulette = bool(useRussianRoulette)
         if LW_flag is not None:
             self.LW_flag = float(LW_flag)
-        self._check(self._lib.mcbrat_specify_parameters(self._ctx, int(self.useRayTracing),
-                                                        int(self.useRussianRoulette), C.c_float(self.LW_flag)))
+        self._push_parameters()
+
+    def _push_parameters(self):
+        # (what the library holds is remembered by content: a step of a small domain is two milliseconds, and the host side
+        # of a call is part of it)
+        token = (self.useRayTracing, self.useRussianRoulette, self.LW_flag)
+        if token != self._param_token:
+            self._check(self._lib.mcbrat_specify_parameters(self._ctx, int(self.useRayTracing),
+                                                            int(self.useRussianRoulette), C.c_float(self.LW_flag)))
+            self._param_token = token
         self._push_intensity()
 
     def _push_intensity(self):
@@ -253,11 +262,12 @@ class Integrator:
         # What is on the device is remembered by CONTENT, never by object identity (CPython reuses the ids of freed
         # objects): a strong reference to the domain, its version counter (addOpticalComponent and the albedo setter
         # bump it) and the parameters the tables depend on.
-        info = dom.getInfo_Domain()  # (expands the component arrays if they are stale, before the token is formed)
         token = (dom._version, self.minInverseTableSize, self.numIntensityDirections() > 0,
                  self.minForwardTableSize, self.useHybridPhaseFunsForIntenCalcs, self.hybridPhaseFunWidth)
         if dom is self._loaded_domain and token == self._domain_token:
             return
+        info = dom.getInfo_Domain()  # (expands the component arrays if they are stale)
+        token = (dom._version,) + token[1:]
         if (info["numX"], info["numY"], info["numZ"]) != self._dims:
             raise McbratError("computeRadiativeTransfer: domain does not match the integrator's grid")
         nc = info["numberOfComponents"]
@@ -319,7 +329,7 @@ class Integrator:
             if numBatches == 1 else int(numPhotonsPerBatch)
         if n < 1:
             raise McbratError("computeRadiativeTransfer: Didn't process any photons.")
-        self.specifyParameters()  # push current flags
+        self._push_parameters()  # push current flags
         self._load_domain(thisDomain)
         self._load_source(incomingPhotons)
         done = C.c_int64(0)
