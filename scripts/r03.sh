@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 3: steps run on the GPU box, selected by name (one script instead of one file per gpurun call):
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash scripts/r03.sh tests poison base'
+# steps: tests bounds poison poison_all base bench bench_lw soak profiles parity ab
 # Every step writes under gpurun_out/r03/ with a time stamp in the file name, so that a failing log is never overwritten.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -93,6 +94,18 @@ step_profiles() {  # the measurement record of the shipped kernels: bench lines,
   bash scripts/pmc_profile.sh landsat r03/prof/pmc_landsat --thr 20 > $P/pmc_landsat.log 2>&1
   find $P -name "*kernel_stats.csv" | xargs -n1 head -3 | cut -c1-200
   echo profiles done
+}
+step_parity() {  # large-sample parity records of the shipped kernels against the oracle's MT mode (-> profiles/r03_parity_*)
+  local P=$OUT/parity; mkdir -p $P
+  python bench.py --cpu-photons-per-core 20000000 --parity-photons 1000000000 --no-secondary > $P/parity_stepcloud.json 2> $P/parity_stepcloud.err; echo "step rc=$?"
+  python bench.py --workload landsatLike128 --steps 3 --warmup 1 --parity-photons 1000000000 --cpu-photons-per-core 20000000 > $P/parity_landsat.json 2> $P/parity_landsat.err; echo "landsat rc=$?"
+  python bench.py --workload radarLike128 --steps 3 --warmup 1 --parity-photons 400000000 --cpu-photons-per-core 16000000 > $P/parity_radar.json 2> $P/parity_radar.err; echo "radar rc=$?"
+  python - $P <<'PY'
+import json,sys
+for w in ("stepcloud","landsat","radar"):
+    d=json.loads(open(sys.argv[1]+"/parity_%s.json"%w).read().strip().splitlines()[-1]); p=d.get("parity") or {}
+    print(w, "%.4g"%d["value"], "bad", d["config"].get("bad_photons"), json.dumps({k:v for k,v in p.items() if not isinstance(v,(list,dict))})[:700])
+PY
 }
 step_ab() {  # A/B of libraries in ab/: scripts/r03.sh ab <case> <thr> lib1 lib2 ...  (case: step | landsat | radar)
   local case=$1 thr=$2; shift 2
