@@ -639,8 +639,9 @@ def main():
         if mine > 0:
             integ.computeRadiativeTransfer(dom, rng, photons, ppb, mine)
         if dist is not None:
-            if a.pipeline:  # order the all-reduce after this step's moments and the next reset after the all-reduce
-                integ.streamWaitDone(torch_stream)
+            # the all-reduce is ordered after this step's moments and the next reset after the all-reduce ON THE DEVICE
+            # (events): the host does not wait for the collective, the timed region ends with a synchronisation
+            integ.streamWaitDone(torch_stream)
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
             if ev:
                 ev[0].record()
@@ -648,10 +649,7 @@ def main():
             if ev:
                 ev[1].record()
                 reduce_events.append(ev)
-            if a.pipeline:
-                integ.waitStream(torch_stream)
-            else:
-                torch.cuda.synchronize()
+            integ.waitStream(torch_stream)
         return 0.0 if (a.pipeline or mine == 0) else integ.lastTraceMs()
 
     def sync():

@@ -85,7 +85,7 @@ step_profiles() {  # the measurement record of the shipped kernels: bench lines,
   python bench.py --workload homogLW20x16 --steps 5 --warmup 1 > $P/bench_lw.json 2> $P/bench_lw.err; echo "bench lw rc=$?"
   python bench.py --workload radarLike128 --steps 3 --warmup 1 --no-cpu-baseline > $P/bench_radar.json 2> $P/bench_radar.err; echo "bench radar rc=$?"
   python bench.py --block-walk 0 --no-cpu-baseline --no-secondary > $P/bench_stepcloud_facebyface.json 2> $P/bench_fbf.err; echo "bench fbf rc=$?"
-  BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-secondary --steps 5 > $P/bench_stepcloud_rccl1.json 2> $P/bench_rccl1.err; echo "bench rccl rc=$?"
+  BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-secondary --steps 20 > $P/bench_stepcloud_rccl1.json 2> $P/bench_rccl1.err; echo "bench rccl rc=$?"
   ( cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_step -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --event-threshold 16 > $P/stats_step.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_landsat -- python3 $ROOT/bench.py --workload landsatLike128 --steps 5 --warmup 1 --no-cpu-baseline --event-threshold 20 > $P/stats_landsat.log 2>&1
