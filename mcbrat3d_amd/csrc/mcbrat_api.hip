@@ -121,6 +121,7 @@ struct mcbrat_ctx {
   int eventThreshold = 16;     // measured optimum 16 (step cloud) .. 32 (128x128x64); see DESIGN.md
   int launchThreshold = 8, surfaceThreshold = 12;  // (exits -- top and surface -- queue together: 12-16 measured best)
   bool surfaceThresholdSet = false;  // by the caller: the block walk otherwise uses its own measured default
+  bool launchThresholdSet = false;   // by the caller: the thermal source otherwise launches 32 lanes at a time (below)
   bool autoTune = true;        // pick eventThreshold by timing short trial launches (once per domain/source)
   bool tuned = false;
   int maxBatchesInFlight = 0;  // 0: bounded by memory
@@ -503,7 +504,10 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   }
   p.counter = c->L().dCounter;
   p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
-  p.launchThreshold = std::max(1, std::min(64, c->launchThreshold));
+  // The thermal source's launch is several hundred instructions (three searches of the emission CDF, double divisions,
+  // sine and cosine in full precision) for photons that live two or three legs: served eight lanes at a time it was half
+  // of config 4's kernel time.  Dead lanes wait for company instead: 32 (config 4: 3.8 -> 5.1e9 photons/s; 24-40 are level).
+  p.launchThreshold = std::max(1, std::min(64, c->launchThresholdSet ? c->launchThreshold : (c->srcKind != 0 ? 32 : c->launchThreshold)));
   p.surfaceThreshold = std::max(1, std::min(64, c->surfaceThreshold));
 }
 
@@ -752,7 +756,9 @@ int autotune(mcbrat_ctx *c, DevParams p, unsigned long long ppb, int nBatches) {
   if (total < want) {
     // too few photons for a meaningful trial: a guess by domain size (few faces per leg on small grids, many on
     // large ones), and the trial is left for a later, larger call
-    c->eventThreshold = plan_launch(c, (size_t)p.slabStride).gridLds ? 16 : 24;
+    // (the thermal source: photons start inside the medium and most end at their first roulette -- few lanes are ever on a
+    // long walk, and waiting for 24 of them starves the event phase: 4-8 measured best on config 4, 24 costs 8 %)
+    c->eventThreshold = c->srcKind != 0 ? 8 : (plan_launch(c, (size_t)p.slabStride).gridLds ? 16 : 24);
     return 0;
   }
   const int nb = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)nBatches, want / std::max<unsigned long long>(1, ppb)));
@@ -1215,7 +1221,7 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   if (privateTallies >= 0) { c->privMode = privateTallies ? 1 : 0; c->gridLdsMode = privateTallies == 2 ? 0 : 1; }
   if (blockSize == 0 || blockSize == 256 || blockSize == 512 || blockSize == 768) c->blockSize = blockSize;
   else if (blockSize > 0) return fail(c, "set_tuning: blockSize must be 0, 256, 512 or 768");
-  if (launchThreshold > 0) c->launchThreshold = launchThreshold;
+  if (launchThreshold > 0) { c->launchThreshold = launchThreshold; c->launchThresholdSet = true; }
   if (surfaceThreshold > 0) { c->surfaceThreshold = surfaceThreshold; c->surfaceThresholdSet = true; }
   if (brickLayout >= 0 && brickLayout <= 2) { if (brickLayout != c->brickMode) c->tuned = false; c->brickMode = brickLayout; }
   return 0;
