@@ -16,7 +16,7 @@ nb = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 doms = [cases.product_domain(c) for c in tstats.lw_cases()][:1]
 run = broadband.SpectralRun(M, doms, minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True)
 it = run.first
-it.setTuning(eventThreshold=int(os.environ.get("THR", "24")), launchThreshold=int(os.environ.get("LTHR", "0")), surfaceThreshold=int(os.environ.get("STHR", "0")))
+it.setTuning(eventThreshold=int(os.environ.get("THR", "0")), launchThreshold=int(os.environ.get("LTHR", "0")), surfaceThreshold=int(os.environ.get("STHR", "0")))
 run.prepare_thermal(tstats.LW_SURFACE_TEMP)
 rng = new_RandomNumberSequence(10)
 ps = run.streams[0]
