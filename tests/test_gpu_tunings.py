@@ -57,6 +57,48 @@ def test_random_tunings_give_the_same_histories(M, seed):
         assert np.array_equal(got[1], base[1], equal_nan=True), (name, tuning)
 
 
+def _run_thermal(M, case, rr, walk, tuning, n=12000):
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    dom = cases.product_domain(case)
+    nx, ny, nz = dom.numX, dom.numY, dom.numZ
+    w = M.new_Weights(nx, ny, nz)
+    M.emission_weighting(dom, w, case["sfc_temp"])
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=rr, LW_flag=1.0)
+    integ.setTuning(**walk, **tuning)
+    photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 9)
+    fates = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
+    integ.resetMoments()
+    integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n // 3, 3)
+    mom = integ.moments().copy()
+    integ.finalize()
+    return fates, mom
+
+
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("seed", range(FUZZ))
+def test_random_tunings_give_the_same_histories_thermal_source(M, seed):
+    """The thermal source has defaults of its own (launch threshold 32, event threshold 8 for calls too small for the trial
+    launches: its launch is the expensive part of a short history).  The library's defaults, the
+    solar source's and a random choice must give every photon the same history and the same moment array."""
+    case, _, _, rr = random_oracle_case(seed)
+    rng = np.random.default_rng(78000 + seed)
+    nx, ny, nz = len(case["xe"]) - 1, len(case["ye"]) - 1, len(case["ze"]) - 1
+    case["temps"] = rng.uniform(230.0, 300.0, (nx, ny, nz))
+    case["sfc_temp"] = float(rng.uniform(250.0, 320.0))
+    case["lambda_um"] = float(rng.uniform(6.0, 14.0))
+    sched = dict(eventThreshold=int(rng.choice([1, 4, 16, 40, 64])), launchThreshold=int(rng.choice([1, 8, 48])),
+                 surfaceThreshold=int(rng.choice([1, 12, 32])), maxBatchesInFlight=int(rng.choice([0, 1, 2])))
+    for name, walk in (("face by face", dict(layerSkip=0, blockWalk=0, privateTallies=0)), ("layers", dict(layerSkip=3, blockWalk=0, privateTallies=0)),
+                       ("block walk", dict(blockWalk=2))):
+        base = _run_thermal(M, case, rr, walk, {})                                                # the thermal source's own defaults
+        for tuning in (dict(eventThreshold=16, launchThreshold=8), sched):                       # the solar source's; a random choice
+            got = _run_thermal(M, case, rr, walk, tuning)
+            for f in base[0].dtype.names:
+                assert np.array_equal(got[0][f], base[0][f], equal_nan=True), (name, f, tuning)
+            assert np.array_equal(got[1], base[1], equal_nan=True), (name, tuning)
+
+
 @pytest.mark.timeout(120, method="thread")
 @pytest.mark.parametrize("seed", range(FUZZ))
 def test_random_call_sequences_async_equals_sync(M, seed):
