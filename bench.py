@@ -46,6 +46,7 @@ from tests import cases  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0  # wave64 VALU instructions per second: 1024 SIMD-32s, one per 2 cycles, 2.4 GHz
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9        # cycles of all 1024 SIMDs per second
 WORKLOADS = {
     # cpu: photons per host core of the cpu_baseline sample (about 20 s of oracle time), parity: photons of the GPU parity run
     "i3rcStepCloud": dict(make=lambda: cases.step_cloud(ssa=0.99), mu0=1.0, phi0=0.0, ppb=100000, batches=100,
@@ -213,6 +214,12 @@ def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False, block
                        "lds_bank_conflict_ratio": rec.get("lds_bank_conflict_ratio"),
                        "l2_requests_per_photon": (rec.get("l2_requests_per_launch") or 0.0) / rec.get("photons_per_launch", per_step),
                        "l2_hit_rate": rec.get("l2_hit_rate"), "source": rec.get("source")}
+        if rec.get("valu_simd_cycles_per_launch"):
+            # the same with every instruction class at the SIMD cycles it was measured to cost on this part (f64 4.3, Philox's 64-bit
+            # multiplies 4.5, transcendentals 8.2 against 2.3 for plain f32 / int32: scripts/valu_rates.hip): the share of the
+            # launch's SIMD cycles in which a vector instruction of this kernel was executing -- the roofline that binds it
+            out["valu"]["simd_busy_frac"] = rec["valu_simd_cycles_per_launch"] * scale / (launch_ms * 1e-3 * SIMD_CYCLES_PER_S)
+            out["valu"]["simd_cycles_per_valu_inst"] = rec["valu_simd_cycles_per_launch"] / rec["valu_insts_per_launch"]
     return out
 
 

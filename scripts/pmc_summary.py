@@ -43,6 +43,19 @@ print(json.dumps({k: v for k, v in t.items() if not k.startswith("_")}, indent=1
 with open(os.path.join(root, "summary.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 
+VALU_CYCLES = {"plain": 2.3, "F64": 4.3, "CVT": 4.25, "INT64": 4.5, "TRANS": 8.2}
+
+
+def valu_cycles(g):
+    """SIMD cycles the launch's vector instructions occupy: every class at its measured issue cost, the rest as plain."""
+    f64 = (g("SQ_INSTS_VALU_ADD_F64") or 0) + (g("SQ_INSTS_VALU_MUL_F64") or 0) + (g("SQ_INSTS_VALU_FMA_F64") or 0)
+    trans = (g("SQ_INSTS_VALU_TRANS_F32") or 0) + (g("SQ_INSTS_VALU_TRANS_F64") or 0)
+    i64, cvt = g("SQ_INSTS_VALU_INT64") or 0, g("SQ_INSTS_VALU_CVT") or 0
+    plain = g("SQ_INSTS_VALU") - f64 - trans - i64 - cvt
+    return (VALU_CYCLES["plain"] * plain + VALU_CYCLES["F64"] * f64 + VALU_CYCLES["CVT"] * cvt + VALU_CYCLES["INT64"] * i64 +
+            VALU_CYCLES["TRANS"] * trans)
+
+
 if len(sys.argv) >= 5 and t:
     workload, ppl, corr = sys.argv[2], int(float(sys.argv[3])), float(sys.argv[4])
     g = lambda k: t.get(k)  # noqa: E731
@@ -58,6 +71,13 @@ if len(sys.argv) >= 5 and t:
            "lds_bank_conflict_ratio": g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") else None,
            "l2_requests_per_launch": g("TCC_REQ_sum"), "l2_hit_rate": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")) if g("TCC_HIT_sum") is not None else None,
            "l2_misses_per_launch": g("TCC_MISS_sum"), "global_atomics_per_launch": g("TCC_ATOMIC_sum"),
+           # instruction classes (a pass of their own) and what they cost the SIMD: cycles per wave64 instruction measured on
+           # this part with 8 waves per SIMD issuing independent instructions (scripts/valu_rates.hip, profiles/r03_valu_rates.txt):
+           # plain f32 / int32 2.3, f64 add / mul / fma 4.3, conversions 4.25 (f64 <-> f32; the counter also holds cheaper ones),
+           # 64-bit integer (v_mad_u64_u32: Philox) 4.5, transcendental (rcp, log, sqrt, sin) 8.2
+           "valu_class_insts_per_launch": {k: g("SQ_INSTS_VALU_" + k) for k in ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F32", "TRANS_F64", "INT64", "INT32", "CVT")}
+           if g("SQ_INSTS_VALU_INT64") is not None else None,
+           "valu_simd_cycles_per_launch": valu_cycles(g) if g("SQ_INSTS_VALU_INT64") is not None else None,
            "fetch_kb_raw": g("FETCH_SIZE"), "write_kb": g("WRITE_SIZE"), "fetch_correction": corr,
            "hbm_bytes_per_launch": (corr * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None else None,
            "source": "rocprofv3 --pmc, separate passes (scripts/pmc_profile.sh), %s; launch = %d photons, fixed event threshold" % (os.path.basename(os.path.normpath(root)), ppl)}
