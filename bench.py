@@ -529,8 +529,8 @@ def dry_run(a, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="i3rcStepCloud", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-photons-per-core", type=int, default=0, help="0 = the workload's default")
     ap.add_argument("--cpu-cores", type=int, default=16)
