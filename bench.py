@@ -165,7 +165,15 @@ def pmc_record(workload):
     if not os.path.exists(path):
         return {}
     with open(path) as f:
-        return json.load(f).get(workload, {})
+        rec = json.load(f).get(workload, {})
+    if rec:
+        # the counters were collected on another box at another time: they describe THIS library only if they were taken from
+        # the same kernel sources (scripts/pmc_summary.py stores their sha256).  A mismatch does not drop the figures -- they are
+        # still the best description on file -- but marks them and withholds the conclusion drawn from them (binding_resource).
+        from mcbrat3d_amd.build import sources_sha256
+        rec = dict(rec)
+        rec["stale"] = rec.get("kernel_sources_sha256") != sources_sha256()
+    return rec
 
 
 def kernel_name(walk, thermal=False, lds_grid=None):
@@ -190,7 +198,7 @@ def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False, block
     scale = per_step / rec.get("photons_per_launch", per_step)
     traffic = rec["hbm_bytes_per_launch"] * scale if rec.get("hbm_bytes_per_launch") is not None else None
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": traffic, "achieved_is": "algorithmic bytes (SURVEY.md 8d) / kernel time: an equivalent rate, not HBM utilisation",
+           "traffic": traffic, "counters_stale": bool(rec.get("stale")) if rec else None, "achieved_is": "algorithmic bytes (SURVEY.md 8d) / kernel time: an equivalent rate, not HBM utilisation",
            "measured_hbm_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic is not None else None,
            "frac_on_touched_bytes": touched * per_step / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "touched_bytes_per_photon": touched,
@@ -200,7 +208,7 @@ def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False, block
                "legs", "crossings", "collisions", "absorbEvents", "topExits", "surfaceHits", "rouletteKills", "rouletteSurvivals")},
            "lanes_per_walk_iteration": cnt["walkLanes"] / max(1, cnt["walkIterations"]),
            "lanes_per_event_phase": cnt["eventLanes"] / max(1, cnt["eventPhases"]),
-           "binding_resource": ("valu_issue" if (workload == "i3rcStepCloud" or rec.get("wave_time_waiting", 1.0) < 0.4) else "l2_requests") if rec else None,
+           "binding_resource": ("valu_issue" if (workload == "i3rcStepCloud" or rec.get("wave_time_waiting", 1.0) < 0.4) else "l2_requests") if (rec and not rec.get("stale")) else None,
            "note": "working set is cache / LDS resident: HBM is not what binds (see valu); DESIGN.md section 5"
                    + ("; --pipeline: kernel durations include waiting for compute units held by the previous launch" if pipeline else "")}
     if rec.get("valu_insts_per_launch"):
@@ -213,7 +221,8 @@ def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False, block
                        "wave_time_issue_stall": rec.get("wave_time_issue_stall"),
                        "lds_bank_conflict_ratio": rec.get("lds_bank_conflict_ratio"),
                        "l2_requests_per_photon": (rec.get("l2_requests_per_launch") or 0.0) / rec.get("photons_per_launch", per_step),
-                       "l2_hit_rate": rec.get("l2_hit_rate"), "source": rec.get("source")}
+                       "l2_hit_rate": rec.get("l2_hit_rate"), "source": rec.get("source"),
+                       "stale": bool(rec.get("stale")), "kernel_sources_sha256": rec.get("kernel_sources_sha256")}
         if rec.get("valu_simd_cycles_per_launch"):
             # the same with every instruction class at the SIMD cycles it was measured to cost on this part (f64 4.3, Philox's 64-bit
             # multiplies 4.5, transcendentals 8.2 against 2.3 for plain f32 / int32: scripts/valu_rates.hip): the share of the
@@ -221,6 +230,46 @@ def roofline_block(workload, cnt, per_step, nc, launch_ms, pipeline=False, block
             out["valu"]["simd_busy_frac"] = rec["valu_simd_cycles_per_launch"] * scale / (launch_ms * 1e-3 * SIMD_CYCLES_PER_S)
             out["valu"]["simd_cycles_per_valu_inst"] = rec["valu_simd_cycles_per_launch"] / rec["valu_insts_per_launch"]
     return out
+
+
+XGMI_LINK_BYTES_PER_S = 153e9  # one xGMI link of an MI355X (7 per GPU), /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def one_rank_allreduce_ms(torch, tensor, device, reps=5):
+    """Duration (CUDA events on torch's stream) of dist.all_reduce(tensor) in a ONE-rank RCCL group: what the collective
+    costs before any byte crosses a link.  Only where no process group exists yet (the N = 1 bench); None if RCCL does not
+    come up -- the projection then carries the link term alone."""
+    try:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            return None
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(free_port())
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)  # (RCCL's banner must not reach stdout: the contract is one JSON line there)
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", device))
+            probe = torch.zeros_like(tensor)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            ms = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(probe)
+                e1.record()
+                torch.cuda.synchronize()
+                ms.append(e0.elapsed_time(e1))
+            dist.destroy_process_group()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
+        return float(sorted(ms)[len(ms) // 2])
+    except Exception as exc:  # noqa: BLE001
+        print("bench.py: one-rank all-reduce probe failed (%s): projection without its fixed cost" % exc, file=sys.stderr)
+        return None
 
 
 def secondary_workload(M, new_rng, device, dist, rank, world, name="landsatLike128", steps=3):
@@ -276,15 +325,21 @@ def secondary_workload(M, new_rng, device, dist, rank, world, name="landsatLike1
     strong = None
 
     def strong_step(i, share_of):
-        lo, mine = _driver.split_batches(w["batches"], rank if share_of == world else 0, share_of)
-        rng.nextPhotonId = (10 ** 6 + i) * per_step + lo * w["ppb"]
+        # (the job cut into a batch count that is a multiple of the rank count: every rank the same number of whole batches)
+        ppb_n, nb_n = _driver.balanced_job(per_step, w["batches"], share_of)
+        lo, mine = _driver.split_batches(nb_n, rank if share_of == world else 0, share_of)
+        rng.nextPhotonId = (10 ** 6 + i) * per_step + lo * ppb_n
         photons.currentPhoton = 1
         integ.resetMoments()
-        integ.computeRadiativeTransfer(dom, rng, photons, w["ppb"], mine)
+        integ.computeRadiativeTransfer(dom, rng, photons, ppb_n, mine)
         if dist is not None:
             dist.all_reduce(moments, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()
         return integ.lastTraceMs()
+
+    def share_photons(n):
+        ppb_n, nb_n = _driver.balanced_job(per_step, w["batches"], n)
+        return _driver.split_batches(nb_n, 0, n)[1] * ppb_n
 
     if world > 1:
         strong_step(0, world)
@@ -303,13 +358,24 @@ def secondary_workload(M, new_rng, device, dist, rank, world, name="landsatLike1
             strong_step(0, n)  # warm
             t1 = time.perf_counter()
             km = sum(strong_step(1 + i, n) for i in range(2))
-            shares[n] = {"photons_per_launch": _driver.split_batches(w["batches"], 0, n)[1] * w["ppb"], "ms_per_launch": 1e3 * (time.perf_counter() - t1) / 2, "kernel_ms": km / 2}
+            shares[n] = {"photons_per_launch": share_photons(n), "ms_per_launch": 1e3 * (time.perf_counter() - t1) / 2, "kernel_ms": km / 2}
         t1ms = shares[1]["ms_per_launch"]
+        # the collective the projection leaves out, priced: the all-reduce of THIS moment array through a one-rank RCCL group,
+        # measured here (launch + one pass over the array), plus what the ring moves over xGMI with N ranks --
+        # 2 (N-1)/N x bytes over one link of ~153 GB/s (MI355X_MICROARCH: xGMI is point to point, a ring is bound per link)
+        ar1 = one_rank_allreduce_ms(torch, moments, device)
+        nbytes = moments.numel() * moments.element_size()
+        ar = {n: (ar1 if ar1 is not None else 0.0) + 1e3 * 2.0 * (n - 1) / n * nbytes / XGMI_LINK_BYTES_PER_S for n in (2, 4, 8)}
         strong = {"job_photons": per_step, "n_gpus": 1, "per_gpu_share_timed_on_one_gpu": shares,
                   "projected_speedup": {str(n): t1ms / shares[n]["ms_per_launch"] for n in (2, 4, 8)},
+                  "projected_speedup_with_allreduce": {str(n): t1ms / (shares[n]["ms_per_launch"] + ar[n]) for n in (2, 4, 8)},
                   "projected_photons_per_s": {str(n): per_step / (shares[n]["ms_per_launch"] * 1e-3) for n in (1, 2, 4, 8)},
-                  "note": "projection from one GPU: time of the share a rank would trace (1/N of the job in one synchronous "
-                          "launch, finish kernels included), all-reduce not included (17 MB over xGMI)"}
+                  "allreduce": {"bytes": nbytes, "one_rank_rccl_ms_measured": ar1, "xgmi_link_GBps_assumed": XGMI_LINK_BYTES_PER_S / 1e9,
+                                "modelled_ms": {str(n): ar[n] for n in (2, 4, 8)}},
+                  "note": "projection from one GPU: time of the share a rank would trace (1/N of the job -- cut into a batch count "
+                          "that is a multiple of N, driver.balanced_job -- in one synchronous launch, finish kernels included); "
+                          "projected_speedup leaves the all-reduce of the moment array out, projected_speedup_with_allreduce adds "
+                          "the one-rank RCCL all-reduce measured here plus the ring's bytes over one xGMI link"}
     res = None
     if rank == 0:
         integ.bindMoments(0)
@@ -380,6 +446,8 @@ def lw_bench(a, M, torch, dist, dev, rank, local_rank, world, rehearse):
     for i in range(a.warmup):
         step(i)
     sync()
+    from mcbrat3d_amd import _capi
+    hip_runtime = _capi.assert_single_hip_runtime()  # (torch's tensor is the moment array the library writes: one runtime serves both)
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
@@ -432,6 +500,7 @@ def lw_bench(a, M, torch, dist, dev, rank, local_rank, world, rehearse):
                                                  "measured apart with one launch at a time",
                           "emitted_flux_W_m2": flux, "event_threshold": run.first.eventThreshold(), "walk": walk,
                           "bad_photons": int(sum(it.badPhotons() for it in run.integrators)),
+                          "hip_runtime": hip_runtime,
                           **({"rehearsal": "gloo, all ranks on cuda:0 -- not a measurement"} if rehearse else {})},
                "roofline": rl}
         if not a.no_cpu_baseline:
@@ -630,21 +699,26 @@ def main():
     rng = new_RandomNumberSequence(10)
     torch_stream = torch.cuda.current_stream(dev).cuda_stream
 
+    # strong scaling: the job cut into a batch count that is a multiple of the rank count (every rank the same number of
+    # whole batches; 100 x 1e6 on 8 ranks -> 104 x 961 538), weak scaling: the workload's own batches on every rank
+    ppb_job, nb_job = driver.balanced_job(per_step, nb, world) if a.scaling == "strong" else (ppb, nb)
+    job_photons = ppb_job * nb_job
+
     reduce_events = []  # (start, end) CUDA events around every all-reduce of the timed steps
 
     def step(i, timed=False):
         # weak scaling: rank r traces photon ids [ (i*world + r) * per_step, +per_step ): disjoint over ranks and steps
         # strong scaling: the step's per_step photons are cut into batches and rank r takes its contiguous share of them
         if a.scaling == "strong":
-            lo, mine = driver.split_batches(nb, rank, world)
-            rng.nextPhotonId = i * per_step + lo * ppb
+            lo, mine = driver.split_batches(nb_job, rank, world)
+            rng.nextPhotonId = i * per_step + lo * ppb_job
         else:
             lo, mine = 0, nb
             rng.nextPhotonId = (i * world + rank) * per_step
         photons.currentPhoton = 1
         integ.resetMoments()
         if mine > 0:
-            integ.computeRadiativeTransfer(dom, rng, photons, ppb, mine)
+            integ.computeRadiativeTransfer(dom, rng, photons, ppb_job, mine)
         if dist is not None:
             # the all-reduce is ordered after this step's moments and the next reset after the all-reduce ON THE DEVICE
             # (events): the host does not wait for the collective, the timed region ends with a synchronisation
@@ -671,6 +745,10 @@ def main():
     for i in range(a.warmup):
         step(i)
     sync()
+    # torch's stream and device pointers are handed to the library above: both must be served by ONE HIP runtime
+    # (torch was imported first, so the library bound to torch's copy; mcbrat3d_amd/_capi.py: hip_runtimes)
+    from mcbrat3d_amd import _capi
+    hip_runtime = _capi.assert_single_hip_runtime()
     t0 = time.perf_counter()
     kernel_ms = 0.0
     for i in range(a.steps):
@@ -737,16 +815,18 @@ def main():
         integ.enableCounters(False)
         launch_ms = kernel_ms / a.steps
         out = {
-            "metric": "photons/sec", "value": (1 if a.scaling == "strong" else world) * per_step * a.steps / elapsed, "unit": "photons/s",
+            "metric": "photons/sec", "value": (job_photons if a.scaling == "strong" else world * per_step) * a.steps / elapsed, "unit": "photons/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32/f64",
             "data": "synthetic",
             "config": {"workload": "%s %dx%dx%d, %d photons/%s/step as %d batches x %d, omega0=0.99 HG g=0.85 mu0=%g"
-                       % (a.workload, nx, ny, nz, per_step, "job" if a.scaling == "strong" else "GPU", nb, ppb, w["mu0"]),
-                       "photons_per_step_per_gpu": per_step // world if a.scaling == "strong" else per_step,
+                       % (a.workload, nx, ny, nz, job_photons if a.scaling == "strong" else per_step, "job" if a.scaling == "strong" else "GPU",
+                          nb_job, ppb_job, w["mu0"]),
+                       "photons_per_step_per_gpu": job_photons // world if a.scaling == "strong" else per_step,
                        "parallelism": "photon batches sharded over %d GPU(s)" % world,
                        "kernel_ms_per_step_per_rank": per_rank_kernel_ms, "allreduce_ms_per_step": allreduce_ms,
                        "bad_photons": integ.badPhotons(),
+                       "hip_runtime": hip_runtime,
                        "world_size": dist.get_world_size() if dist is not None else 1,
                        **({"rehearsal": "gloo, all ranks on cuda:0 -- not a measurement"} if rehearse else {}),
                        "photons_in_reduced_moments_last_step": reduced_photons,

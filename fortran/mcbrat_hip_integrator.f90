@@ -29,7 +29,13 @@ module mcbrat_hip_integrator
             specifyIntensity, setForwardTable, reportIntensity, forwardTableLegendre, &
             setSurfaceDescription, setWalkOptions, getFrequencyDistr, shareMoments, chainAfter, numBadPhotons
 
+  ! MCBRAT_ABI_VERSION of include/mcbrat.h this module was written against: mcbrat_counters has 15 fields (badPhotons) since 2
+  integer(c_int), parameter :: expectedAbiVersion = 2
   interface
+    function mcbrat_abi_version() bind(C, name="mcbrat_abi_version") result(v)
+      import :: c_int
+      integer(c_int) :: v
+    end function
     function mcbrat_create(device) bind(C, name="mcbrat_create") result(ctx)
       import :: c_ptr, c_int
       integer(c_int), value :: device
@@ -245,6 +251,11 @@ contains
     integer,               intent(in) :: device
     integer,               intent(out):: ierr
     type(integrator) :: new
+    new%ctx = c_null_ptr
+    if (mcbrat_abi_version() /= expectedAbiVersion) then
+      ierr = 2   ! "new_Integrator: libmcbrat_hip.so is of another ABI version than this module" (a stale build: the
+      return     !  dimension(15) counter buffer of numBadPhotons would not be what the library writes)
+    end if
     new%ctx = mcbrat_create(int(device, c_int))
     if (.not. c_associated(new%ctx)) then
       ierr = 1   ! "new_Integrator: no usable HIP device" -- there is no CPU fallback

@@ -4,6 +4,7 @@ There is no CPU fallback: if libmcbrat_hip.so is missing or no HIP device is
 usable, importing the symbols or creating a context raises."""
 import ctypes as C
 import os
+import re
 
 import numpy as np
 
@@ -83,22 +84,69 @@ SYMBOLS = {
 }
 
 
+ABI_VERSION = 2  # MCBRAT_ABI_VERSION of include/mcbrat.h this binding was written against (Counters has badPhotons since 2)
+
+
+def hip_runtimes():
+    """Distinct HIP runtime libraries (libamdhip64) mapped into this process, as paths.
+
+    The product links ROCm's runtime by SONAME (libamdhip64.so.7, RUNPATH /opt/rocm); PyTorch ships a copy of its own and asks
+    for it by another name (libamdhip64.so, RPATH $ORIGIN).  Loaded after PyTorch the product binds to PyTorch's copy (same
+    SONAME, already loaded): ONE runtime.  Loaded before it, PyTorch maps its copy beside ROCm's: TWO runtimes in one
+    process, and a stream or device pointer of one handed to the other (bench.py, driver.run: RCCL on the moment buffer) is
+    a handle of a different library.  INTEGRATION.md, "One HIP runtime"."""
+    found = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                m = re.search(r"(/\S*libamdhip64[^\s]*)", line)
+                if m:
+                    found.add(os.path.realpath(m.group(1)))
+    except OSError:
+        pass
+    return sorted(found)
+
+
+def assert_single_hip_runtime():
+    """Raises unless exactly one HIP runtime is mapped; returns its path.  Called when the library is loaded, and again by
+    everything that passes PyTorch objects (streams, tensors) to it."""
+    rts = hip_runtimes()
+    if len(rts) > 1:
+        raise McbratError("two HIP runtimes in one process (%s): import torch BEFORE the first call into mcbrat3d_amd, so that "
+                          "libmcbrat_hip.so binds to the runtime PyTorch brings (INTEGRATION.md, 'One HIP runtime')" % ", ".join(rts))
+    return rts[0] if rts else None
+
+
 def lib():
-    """The loaded native library; raises if it has not been built."""
+    """The loaded native library; raises if it has not been built, if its ABI is not the one this binding expects, or if
+    loading it has left two HIP runtimes in the process."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise McbratError("%s is missing: build it with `python -m mcbrat3d_amd.build` "
                               "(there is no CPU fallback)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
+        old = bool(os.environ.get("MCBRAT_LIB_OLD"))  # A/B runs against a library built from an earlier round's sources: MCBRAT_LIB=... MCBRAT_LIB_OLD=1
         for name, (res, args) in SYMBOLS.items():
-            if os.environ.get("MCBRAT_LIB_OLD") and not hasattr(L, name):
-                continue  # (A/B runs against a library built from an earlier round's sources: MCBRAT_LIB=... MCBRAT_LIB_OLD=1)
+            if old and not hasattr(L, name):
+                continue
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        # (a stale or foreign build: the size of mcbrat_counters and the meaning of its last field depend on the version --
+        # an ABI-1 library would leave badPhotons unwritten and every "nothing was dropped" check would pass vacuously)
+        got = L.mcbrat_abi_version()
+        if got != ABI_VERSION and not old:
+            raise McbratError("%s has ABI version %d, this binding expects %d: rebuild it (`python -m mcbrat3d_amd.build --force`), "
+                              "or set MCBRAT_LIB_OLD=1 for an A/B run against an older library" % (LIB_PATH, got, ABI_VERSION))
+        L._mcbrat_abi = got
         _lib = L
+        assert_single_hip_runtime()
     return _lib
+
+
+def lib_abi():
+    return lib()._mcbrat_abi
 
 
 def ptr(a):

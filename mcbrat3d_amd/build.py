@@ -17,6 +17,17 @@ DEPS = SOURCES + ["mcbrat_kernels.hip", "mcbrat_blockwalk.hip", "mcbrat_device.h
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 
+def sources_sha256():
+    """sha256 over the sources the library is built from (DEPS, in order): stored with every counter record
+    (scripts/pmc_summary.py -> profiles/pmc_shipped.json) so that bench.py can tell counters of these kernels from stale ones."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

@@ -16,6 +16,20 @@ def split_batches(numBatches, rank, world):
     return lo, base + (1 if rank < extra else 0)
 
 
+def balanced_job(totalPhotons, numBatches, world):
+    """(photons per batch, batches) of a job of about totalPhotons photons cut so that every rank gets the SAME number of
+    whole batches: the smallest multiple of `world` that is >= numBatches.  The reference's master deals work units of
+    numPhotonsPerBatch photons to whichever worker is free (monteCarloDriver.f95:665-880), which balances by itself; a
+    static split of 100 batches over 8 ranks is 13/13/13/13/12/12/12/12 -- the slowest rank carries 4 % more than the
+    mean.  Batches stay whole (they are the statistical units of the standard errors, :1188-1228, and whole batches keep an
+    N-rank run bitwise equal to the one-rank run of the same batches), so the batch count moves instead: 100 batches of
+    1e6 on 8 ranks become 104 of 961 538 (the job is then 99 999 952 photons; batches are of equal size in the C ABI)."""
+    world = max(1, int(world))
+    nb = -(-int(numBatches) // world) * world
+    ppb = max(1, int(round(float(totalPhotons) / nb)))
+    return ppb, nb
+
+
 def unpack_moments(buf, nx, ny, nz, nDirections=None):
     """header(8) + S1[M] + S2[M] -> dict name -> (S1, S2) in [ix, iy(, iz | direction)] index order."""
     ncol, nvox = nx * ny, nx * ny * nz
@@ -57,20 +71,62 @@ def statistics(moments, solarFlux=1.0):
     return res
 
 
+class UnitCounter:
+    """A counter of work-unit ids shared by the ranks of a job: next() hands out 0, 1, 2, ... exactly once each, to
+    whichever rank asks first -- the reference's master (monteCarloDriver.f95:665-880 deals work units to the worker that
+    is free; worker side :903-918) without a master rank and without its MPI_SEND / MPI_PROBE traffic.  The count lives in
+    the process group's key-value store (its `add` is atomic); host side only, nothing crosses the GPUs' links."""
+    _sequence = 0  # every rank creates its counters in the same order: the key is the same on all of them
+
+    def __init__(self, dist):
+        from torch.distributed import distributed_c10d
+        self.store = distributed_c10d._get_default_store()
+        UnitCounter._sequence += 1
+        self.key = "mcbrat3d_amd/units/%d" % UnitCounter._sequence
+
+    def next(self):
+        return int(self.store.add(self.key, 1)) - 1
+
+
 def run(integrator, domain, photons, numPhotonsPerBatch, numBatches, randomNumbers, solarFlux=1.0, dist=None,
-        moments_tensor=None):
+        moments_tensor=None, schedule="static", unitBatches=0):
     """Worker loop + reduction.  `dist` is torch.distributed (initialised) or None.
     With dist, `moments_tensor` must be a CUDA double tensor of 8 + 2*M elements that the
-    integrator accumulates into (bindMoments) and that is all-reduced in place."""
+    integrator accumulates into (bindMoments) and that is all-reduced in place.
+
+    schedule = "static" (default): rank r traces its contiguous block of batches in ONE call (split_batches; cut the job
+    with balanced_job and every rank's block is the same size).  Which rank traced which batch is fixed, so a run is
+    reproducible to the last bit.
+    schedule = "dynamic": batches are dealt out in units of `unitBatches` (default: about eight units per rank) from a
+    shared counter to whichever rank is free, as the reference's master does -- for jobs whose ranks or units are not
+    alike (a busy GPU, wavelengths of unlike optical depth).  Every unit is one synchronous call, so each pays the drain
+    of its launch: units should be large next to it.  The same photons are traced whatever the
+    assignment; sums over batches then depend on it in the last bits."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
-    lo, nb = split_batches(numBatches, rank, world)
     integrator.resetMoments()
     first = randomNumbers.nextPhotonId
-    if nb > 0:
-        randomNumbers.nextPhotonId = first + lo * numPhotonsPerBatch
-        photons.currentPhoton = 1
-        photons.numberOfPhotons = max(photons.numberOfPhotons, nb * numPhotonsPerBatch)
-        integrator.computeRadiativeTransfer(domain, randomNumbers, photons, numPhotonsPerBatch, nb)
+    if schedule == "dynamic" and dist is not None and world > 1:
+        per = int(unitBatches) if unitBatches and unitBatches > 0 else max(1, int(numBatches) // (8 * world))
+        nUnits = -(-int(numBatches) // per)
+        counter = UnitCounter(dist)
+        photons.numberOfPhotons = max(photons.numberOfPhotons, numBatches * numPhotonsPerBatch)
+        while True:
+            u = counter.next()
+            if u >= nUnits:
+                break
+            b0 = u * per
+            randomNumbers.nextPhotonId = first + b0 * numPhotonsPerBatch
+            photons.currentPhoton = 1
+            integrator.computeRadiativeTransfer(domain, randomNumbers, photons, numPhotonsPerBatch, min(per, numBatches - b0))
+    else:
+        if schedule not in ("static", "dynamic"):
+            raise ValueError("driver.run: schedule must be 'static' or 'dynamic'")
+        lo, nb = split_batches(numBatches, rank, world)
+        if nb > 0:
+            randomNumbers.nextPhotonId = first + lo * numPhotonsPerBatch
+            photons.currentPhoton = 1
+            photons.numberOfPhotons = max(photons.numberOfPhotons, nb * numPhotonsPerBatch)
+            integrator.computeRadiativeTransfer(domain, randomNumbers, photons, numPhotonsPerBatch, nb)
     randomNumbers.nextPhotonId = first + numBatches * numPhotonsPerBatch
     if dist is not None and world > 1:
         import torch

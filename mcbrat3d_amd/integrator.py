@@ -397,7 +397,10 @@ class Integrator:
     def counters(self):
         c = Counters()
         self._check(self._lib.mcbrat_get_counters(self._ctx, C.addressof(c)))
-        return c.as_dict()
+        d = c.as_dict()
+        if getattr(self._lib, "_mcbrat_abi", 2) < 2:
+            d["badPhotons"] = None  # (an A/B library from before ABI 2 does not write the field: unknown, not zero)
+        return d
 
     def lastTraceMs(self):
         return float(self._lib.mcbrat_last_trace_ms(self._ctx))

@@ -14,6 +14,9 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcbrat3d_amd.build import sources_sha256  # noqa: E402
+
 root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
 files = []
@@ -80,6 +83,8 @@ if len(sys.argv) >= 5 and t:
            "valu_simd_cycles_per_launch": valu_cycles(g) if g("SQ_INSTS_VALU_INT64") is not None else None,
            "fetch_kb_raw": g("FETCH_SIZE"), "write_kb": g("WRITE_SIZE"), "fetch_correction": corr,
            "hbm_bytes_per_launch": (corr * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None else None,
+           # which kernels these counters belong to: bench.py compares with the sources beside it and marks the record stale on mismatch
+           "kernel_sources_sha256": sources_sha256(),
            "source": "rocprofv3 --pmc, separate passes (scripts/pmc_profile.sh), %s; launch = %d photons, fixed event threshold" % (os.path.basename(os.path.normpath(root)), ppl)}
     shipped = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_shipped.json")
     cur = {}

@@ -36,6 +36,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.timeout(GPU_DEFAULT_TIMEOUT, method="thread"))
 
 
+@pytest.fixture(autouse=True, scope="session")
+def _one_hip_runtime():
+    """ONE HIP runtime per process, asserted (mcbrat3d_amd/_capi.py: hip_runtimes): PyTorch is imported above, before anything
+    loads libmcbrat_hip.so, so the library binds to PyTorch's copy of libamdhip64.  Two copies -- the product loaded first,
+    PyTorch after it -- would make every stream and device pointer the tests pass between the two a handle of another library.
+    Checked when the session starts (nothing loaded yet, or one) and when it ends (everything loaded)."""
+    from mcbrat3d_amd import _capi
+    _capi.assert_single_hip_runtime()
+    yield
+    _capi.assert_single_hip_runtime()
+
+
 @pytest.fixture(autouse=True)
 def _no_photon_dropped_by_a_loop_bound(request):
     """Every integrator a GPU test finalises must report badPhotons == 0 (include/mcbrat.h: photons dropped because a
