@@ -179,6 +179,9 @@ def pmc_record(workload):
 def kernel_name(walk, thermal=False, lds_grid=None):
     """The tracing kernel a flux run of this walk mode launches (mcbrat_api.hip: launch_trace)."""
     if walk.get("blockWalk"):
+        if walk.get("widePlan"):
+            return "trace_block_kernel (mcbrat_blockwalk.hip: block walk, one workgroup of 1024 lanes per CU, tallies + tables%s in LDS%s)" % (
+                " + block numbers, optics in global memory" if walk.get("opticsInGlobalMemory") else " + grid", ", thermal source" if thermal else "")
         return "trace_block_kernel (mcbrat_blockwalk.hip: block walk, grid + tallies + tables in LDS%s)" % (", thermal source" if thermal else "")
     return "trace_kernel (mcbrat_kernels.hip: %s%s%s)" % (
         "layer-skipping walk" if walk.get("layerSkip") else "face-by-face walk",

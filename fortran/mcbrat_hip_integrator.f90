@@ -27,10 +27,10 @@ module mcbrat_hip_integrator
             resetMoments, getMoments, momentsLength, lastMessage, &
             inverseTableLegendre, lastTraceMilliseconds, setAsynchronous, synchronize, &
             specifyIntensity, setForwardTable, reportIntensity, forwardTableLegendre, &
-            setSurfaceDescription, setWalkOptions, getFrequencyDistr, shareMoments, chainAfter, numBadPhotons
+            setSurfaceDescription, setWalkOptions, setOption, getFrequencyDistr, shareMoments, chainAfter, numBadPhotons
 
   ! MCBRAT_ABI_VERSION of include/mcbrat.h this module was written against: mcbrat_counters has 15 fields (badPhotons) since 2
-  integer(c_int), parameter :: expectedAbiVersion = 2
+  integer(c_int), parameter :: expectedAbiVersion = 3
   interface
     function mcbrat_abi_version() bind(C, name="mcbrat_abi_version") result(v)
       import :: c_int
@@ -196,6 +196,13 @@ module mcbrat_hip_integrator
       import :: c_ptr, c_int, c_int32_t
       type(c_ptr), value :: ctx
       integer(c_int32_t), value :: layerSkip, blockWalk
+      integer(c_int) :: rc
+    end function
+    function mcbrat_set_option(ctx, name, value) bind(C, name="mcbrat_set_option") result(rc)
+      import :: c_ptr, c_int, c_int32_t, c_char
+      type(c_ptr), value :: ctx
+      character(kind=c_char), dimension(*), intent(in) :: name
+      integer(c_int32_t), value :: value
       integer(c_int) :: rc
     end function
     function mcbrat_frequency_distribution(ctx, seed, firstDraw, numLambda, cdf, totalPhotons, distribution) &
@@ -453,6 +460,15 @@ contains
     integer, intent(out) :: ierr
     ierr = mcbrat_set_walk_options(this%ctx, merge(1_c_int32_t, 0_c_int32_t, layerSkip), merge(1_c_int32_t, 0_c_int32_t, blockWalk))
   end subroutine setWalkOptions
+  ! Scheduling options by name (include/mcbrat.h: mcbrat_set_option), e.g. setOption(this, "twoPhotons", 0, ierr); none of them
+  ! changes a result.  The reference has no counterpart.
+  subroutine setOption(this, name, value, ierr)
+    type(integrator), intent(inout) :: this
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: value
+    integer, intent(out) :: ierr
+    ierr = mcbrat_set_option(this%ctx, trim(name) // c_null_char, int(value, c_int32_t))
+  end subroutine setOption
   ! computeRT's nBad (Integrators/monteCarloRadiativeTransfer.f95:420, :562-563: photons dropped because their step was not
   ! positive): here the photons dropped because a loop bound of the kernels was reached, since this integrator was created
   ! (mcbrat_counters.badPhotons, include/mcbrat.h).  Synchronises.

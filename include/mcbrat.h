@@ -28,7 +28,7 @@ extern "C" {
 
 #define MCBRAT_MAX_COMPONENTS 8
 #define MCBRAT_MAX_DIRECTIONS 64 /* intensity directions per run */
-#define MCBRAT_ABI_VERSION 2
+#define MCBRAT_ABI_VERSION 3
 
 typedef struct mcbrat_ctx mcbrat_ctx;
 
@@ -175,6 +175,10 @@ int mcbrat_get_moments(mcbrat_ctx *ctx, double *hostBuffer);
  * are only collected when enabled; they cost a few percent). */
 int mcbrat_enable_counters(mcbrat_ctx *ctx, int32_t enable);
 int mcbrat_get_counters(mcbrat_ctx *ctx, mcbrat_counters *out); /* synchronises; badPhotons is valid whether or not counters are enabled */
+/* What was dropped FIRST since the context was created (badPhotons > 0): which bound fired, in which kernel, the photon's id,
+ * state and leg count -- one occurrence is then enough to trace that photon again alone and find the cause (computeRT only counts, :562-563).  An empty
+ * string while nothing was dropped.  Synchronises; the text lives until the next call of this function on the context.  ABI 3. */
+const char *mcbrat_first_drop(mcbrat_ctx *ctx);
 float mcbrat_last_trace_ms(const mcbrat_ctx *ctx);
 /* Asynchronous mode.  A launch ends with its longest photon history, so every call carries a fixed
  * drain time; a caller that issues many calls -- the reference's driver calls
@@ -205,12 +209,26 @@ int mcbrat_chain_after(mcbrat_ctx *ctx, mcbrat_ctx *previous);
 /* Tuning knobs (negative = leave unchanged): workgroups per CU (0 = occupancy query), number of
  * walking lanes below which a wave serves its waiting lanes (0 = choose by timing short trial
  * launches, the default), batches in flight per launch
- * (0 = memory bound), LDS-private tallies on/off, workgroup size (0 = automatic, 256, 512, 768), and how
+ * (0 = memory bound), privateTallies (0 global atomics; 1 the library's plan: tallies private to a workgroup in LDS where the
+ * slab fits beside a second workgroup, else the wide plan -- one workgroup of 1024 lanes per compute unit with up to its
+ * whole 160 KB of LDS -- else global atomics; 2 private tallies without the optical grid in LDS; 3 as 1 without the wide plan;
+ * 4 the wide plan even where the shared one would do; 5 as 4 with the per-cell optics left in global memory),
+ * workgroup size (0 = automatic, 256, 512, 768; a fixed size rules the wide plan out), and how
  * many idle / surface lanes queue up before launches / surface reflections are served; brickLayout:
  * 0 dense optical grids, 1 4x4x4 bricks with unstored background bricks, 2 automatic (default). */
 int mcbrat_set_tuning(mcbrat_ctx *ctx, int32_t blocksPerCU, int32_t eventThreshold, int32_t maxBatchesInFlight,
                       int32_t privateTallies, int32_t blockSize, int32_t launchThreshold, int32_t surfaceThreshold,
                       int32_t brickLayout);
+
+/* Scheduling options by name (none of them changes a result: the same photons, the same arithmetic per photon, integer
+ * tallies -- tests/test_gpu_tunings.py holds random choices against the defaults bit for bit).  ABI 3.
+ *   "twoPhotons"    1 (default) / 0: large flux runs (dense grid in global memory, solar source) keep TWO photons per lane in
+ *                   registers, so that a lane whose photon has stopped walking goes on with its other one (trace_kernel<..., TWO>)
+ *   "pairThreshold" parked photons waiting for their collision that make a wave run another event phase at once (65: never)
+ *   "swapThreshold" lanes whose photon has stopped while their parked one could walk that make the walk loop change them over
+ *   "jumpThreshold", "crossThreshold"  lanes queued before transitions of the layer-skipping walk / block crossings are served
+ * The reference has no counterpart (its loop is one photon at a time, monteCarloRadiativeTransfer.f95:463-466). */
+int mcbrat_set_option(mcbrat_ctx *ctx, const char *name, int32_t value);
 
 /* specifyParameters(surfaceBDRF = new_SurfaceDescription(surfaceParameters, xPosition, yPosition))
  * (Integrators/monteCarloRadiativeTransfer.f95:1173-1176, src/surfaceProperties.f95:58-94): a reflecting surface whose
@@ -248,7 +266,10 @@ int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t blockWal
  * layerSkip, bit 1 the block walk (asked for AND applicable: grid, tallies and tables fit in LDS, blocks hold four
  * cells or more on average, no radiance directions), bit 2 the clear-air flight (asked for and possible: brick columns
  * exist, the background is thin enough or layerSkip = 3, no radiance directions, the grid is not held in LDS and the
- * flight's tables fit beside the rest), bit 3 the blockWalk option as set.  Before grid and optics are loaded: the options. */
+ * flight's tables fit beside the rest), bit 3 the blockWalk option as set, bit 6 tallies private to a workgroup in LDS,
+ * bit 4 the wide plan (a tally slab too large to share a compute unit's LDS: one workgroup of 1024 lanes per compute unit
+ * owns up to its whole 160 KB), bit 5 the block walk with the per-cell optics left in global memory (extinction per block
+ * in LDS).  Before grid and optics are loaded: the options. */
 int mcbrat_get_walk_mode(const mcbrat_ctx *ctx);
 
 /* The event threshold in use (after the first call of a domain: the one chosen by the trial launches). */

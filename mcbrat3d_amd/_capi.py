@@ -71,6 +71,8 @@ SYMBOLS = {
     "mcbrat_chain_after": (C.c_int, [_vp, _vp]),
     "mcbrat_set_tuning": (C.c_int, [_vp] + [_i32] * 8),
     "mcbrat_set_walk_options": (C.c_int, [_vp, _i32, _i32]),
+    "mcbrat_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
+    "mcbrat_first_drop": (C.c_char_p, [_vp]),
     "mcbrat_get_walk_mode": (C.c_int, [_vp]),
     "mcbrat_moments_device_pointer": (_vp, [_vp]),
     "mcbrat_frequency_distribution": (C.c_int, [_vp, _u64, _u64, _i32, _vp, _i64, _vp]),
@@ -84,7 +86,7 @@ SYMBOLS = {
 }
 
 
-ABI_VERSION = 2  # MCBRAT_ABI_VERSION of include/mcbrat.h this binding was written against (Counters has badPhotons since 2)
+ABI_VERSION = 3  # MCBRAT_ABI_VERSION of include/mcbrat.h this binding was written against (badPhotons since 2, mcbrat_set_option since 3)
 
 
 def hip_runtimes():

@@ -38,11 +38,14 @@ struct mcbrat_ctx {
   hipEvent_t lastDone = nullptr;   // evDone of the most recent call: the next finish chain waits for it
   hipEvent_t evExternal = nullptr; // recorded on a caller's stream by mcbrat_wait_stream
   bool externalPending = false;
-  mcbrat_ctx *chainAfter = nullptr; // mcbrat_chain_after: the context whose finish chain this context's next one follows
-  hipEvent_t chainSnapshot = nullptr; // ... and what it had enqueued when the chain was asked for (its lastDone then)
+  bool chainAfter = false;          // mcbrat_chain_after: this context's next finish chain follows another context's
+  hipEvent_t chainSnapshot = nullptr; // ... namely what that context had enqueued when the chain was asked for: an event of THIS context,
+                                    // recorded on the other's stream at that moment (no handle of the other context is kept: it may be
+                                    // destroyed, or go on to other calls, before this context's next one)
+  hipEvent_t evChain = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing, eventPool;  // asynchronous mode: kernel brackets not yet read
   Lane &L() { return lane[cur]; }
-  std::string err;
+  std::string err, dropText;
   int numCUs = 256;
   size_t ldsPerCU = 160 * 1024;
   // grid
@@ -71,9 +74,14 @@ struct mcbrat_ctx {
   // block walk (mcbrat_blockwalk.hip)
   uint32_t *dBlockRec = nullptr;
   uint16_t *dBlockOf = nullptr;
+  float *dBlockExt = nullptr;  // [nBlocks] extinction of each block
   int nBlocks = 0;
   int crossThreshold = 8;      // MCBRAT_CROSS_THRESHOLD
   int jumpThreshold = 8;       // MCBRAT_JUMP_THRESHOLD
+  // two photons per lane (trace_kernel<..., TWO>; large flux runs: dense grid in global memory, solar source)
+  int twoPhotons = 0;          // (off: measured 38 % slower) MCBRAT_TWO_PHOTONS / mcbrat_set_option("twoPhotons")
+  int pairThreshold = 16;      // MCBRAT_PAIR_THRESHOLD / "pairThreshold"
+  int swapThreshold = 24;      // MCBRAT_SWAP_THRESHOLD / "swapThreshold"
   float *dExtB = nullptr, *dCumB = nullptr, *dSsaB = nullptr, *dBgExt = nullptr, *dBgCum = nullptr, *dBgSsa = nullptr;
   uint16_t *dPfiB = nullptr, *dBgPfi = nullptr;
   int nbx = 0, nby = 0, nbz = 0;
@@ -126,6 +134,9 @@ struct mcbrat_ctx {
   bool tuned = false;
   int maxBatchesInFlight = 0;  // 0: bounded by memory
   int privMode = 1;            // 1: LDS-private tallies when the slab fits, 0: always global atomics
+  int wideDefault = 1;         // MCBRAT_WIDE
+  int wideMode = 1;            // 1: a tally slab too large for the shared plan may take a compute unit's whole LDS (one workgroup of 1024 lanes per CU;
+                               //    MCBRAT_WIDE=0 / set_tuning(privateTallies = 3) turn it off: such domains then tally with global atomics)
   int blockSize = 0;           // 0: chosen by plan_launch
   unsigned long long tuneTrialPhotons = 1ull << 26;  // MCBRAT_TUNE_PHOTONS
   int regularWalk = 1;         // equally spaced grids: incremental face distances (MCBRAT_REGULAR_WALK=0 turns it off)
@@ -140,7 +151,8 @@ struct mcbrat_ctx {
   unsigned long long *hBad = nullptr;   // pinned host copy, written by the last finish kernel of every call (hBadDev: the same word as the device sees it)
   unsigned long long *hBadDev = nullptr;
   unsigned maxEvents = 1u << 24, maxEventsNaN = 1u << 20, watchdog = 1u << 20;  // MCBRAT_MAX_EVENTS, MCBRAT_MAX_EVENTS_NAN, MCBRAT_WATCHDOG
-  int legacyTies = 0;                   // MCBRAT_TEST_LEGACY_TIES (tests only)
+  int legacyTies = 0;
+  float testRayMaxLen = 0.0f;  // TEST ONLY (MCBRAT_TEST_RAY_MAX_LEN, km): replaces the geometric bound on a view ray's length                   // MCBRAT_TEST_LEGACY_TIES (tests only)
   // mcbrat_frequency_distribution's device buffers, kept and grown with numLambda
   double *dFreqCdf = nullptr;
   unsigned long long *dFreqCounts = nullptr;
@@ -409,13 +421,17 @@ int build_blocks(mcbrat_ctx *c, const std::vector<float> &e) {
   c->nBlocks = 0;
   if (c->dBlockRec) { (void)hipFree(c->dBlockRec); c->dBlockRec = nullptr; }
   if (c->dBlockOf) { (void)hipFree(c->dBlockOf); c->dBlockOf = nullptr; }
+  if (c->dBlockExt) { (void)hipFree(c->dBlockExt); c->dBlockExt = nullptr; }
   // only grids that can live in LDS are walked this way (plan_launch decides); bounds are packed in 16 bits
   if (nvox > 65536 || nx > 65535 || ny > 65535 || nz > 65535) return 0;
   std::vector<uint16_t> of(nvox);
   std::vector<uint32_t> rec(4 * nvox);
   int32_t nb = 0;
   if (mcbrat_block_decomposition(nx, ny, nz, e.data(), of.data(), rec.data(), &nb) != 0) return 0;  // (more than 65535 blocks: face-by-face walk)
-  if (upload(c, &c->dBlockRec, rec.data(), (size_t)4 * nb) || upload(c, &c->dBlockOf, of.data(), of.size())) return 1;
+  std::vector<float> blockExt((size_t)nb, 0.0f);
+  for (size_t v = 0; v < nvox; ++v) blockExt[of[v]] = e[v];  // (one value per block by construction)
+  if (upload(c, &c->dBlockRec, rec.data(), (size_t)4 * nb) || upload(c, &c->dBlockOf, of.data(), of.size()) ||
+      upload(c, &c->dBlockExt, blockExt.data(), blockExt.size())) return 1;
   c->nBlocks = nb;
   return 0;
 }
@@ -490,9 +506,11 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   for (int k = 0; k < c->nc && c->nDir > 0; ++k) { p.fwdOffset[k] = c->fwdOffset[k]; p.fwdNAngles[k] = c->fwdNAngles[k]; }
   p.useHybrid = c->useHybrid; p.numOrdersOrig = c->numOrdersOrig; p.useRRIntensity = c->useRRIntensity; p.zetaMin = c->zetaMin;
   p.limitContrib = c->limitContrib; p.maxContrib = c->maxContrib;
-  p.nBlocks = c->nBlocks; p.blockRec = reinterpret_cast<const uint4 *>(c->dBlockRec); p.blockOf = c->dBlockOf;
+  p.nBlocks = c->nBlocks; p.blockRec = reinterpret_cast<const uint4 *>(c->dBlockRec); p.blockOf = c->dBlockOf; p.blockExt = c->dBlockExt;
   p.crossThreshold = std::max(1, std::min(64, c->crossThreshold));
   p.jumpThreshold = std::max(1, std::min(64, c->jumpThreshold));
+  p.pairThreshold = std::max(1, std::min(65, c->pairThreshold));  // (65: never)
+  p.swapThreshold = std::max(1, std::min(65, c->swapThreshold));
   p.bad = c->dBad;
   p.maxEvents = c->maxEvents; p.maxEventsNaN = std::min(c->maxEventsNaN, c->maxEvents); p.watchdog = c->watchdog;  // (the kernels test the smaller one first)
   p.legacyTies = c->legacyTies;
@@ -501,6 +519,7 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
     float muMin = 1.0f;
     for (int i = 0; i < c->nDir; ++i) muMin = std::min(muMin, std::fabs(c->dirData[(size_t)8 * i + 2]));
     p.rayMaxLen = (float)((p.zMax - p.z0) / (double)std::max(muMin, FLT_MIN)) * 1.0001f + 1e-6f;
+    if (c->testRayMaxLen > 0.0f) p.rayMaxLen = c->testRayMaxLen;  // TEST ONLY (MCBRAT_TEST_RAY_MAX_LEN): drive the bound on purpose
   }
   p.counter = c->L().dCounter;
   p.eventThreshold = std::max(1, std::min(64, c->eventThreshold));
@@ -511,9 +530,10 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.surfaceThreshold = std::max(1, std::min(64, c->surfaceThreshold));
 }
 
-constexpr size_t kLdsBudget = 64 * 1024;      // default dynamic-LDS limit per workgroup
-constexpr size_t kTableLdsLimit = 48 * 1024;   // tables above this stay in L2
-constexpr size_t kPrivSlabLimit = 32 * 1024;   // private tally slab above this -> global atomics
+constexpr size_t kLdsBudget = 64 * 1024;      // dynamic LDS of a workgroup that shares its compute unit with another one (two workgroups of 768 lanes, four of 256)
+constexpr size_t kTableLdsLimit = 48 * 1024;   // tables above this stay in L2 (shared plans)
+constexpr size_t kPrivSlabLimit = 32 * 1024;   // private tally slab above this -> the wide plan, else global atomics
+constexpr size_t kStaticLds = 6 * 1024;        // room kept for the kernels' static __shared__ arrays (descriptors; trace_kernel's s_flyTC is 4 KB at 1024 lanes)
 
 // LDS of the per-layer tables: extinction (float), run (int), cumulative optical depth (double, nz + 1 padded to even);
 // clear-air flight: background extinction (float), the brick columns' cloud ranges as heights (2 floats) and layers (u16)
@@ -530,12 +550,25 @@ bool flight_wanted(const mcbrat_ctx *c) {
 struct LaunchPlan {
   bool tblLds, priv, brick, gridLds;
   bool fly;  // clear-air flight: dense grid in global memory, flux run, tables built, room in LDS
+  // Wide plan (MI355X: 160 KB of LDS per compute unit): a tally slab too large to share a compute unit's LDS with a second
+  // workgroup -- the broadband 20 x 20 x 20 domain's is 70 KB -- gets the compute unit to itself: ONE workgroup of 1024 lanes
+  // (16 waves, 4 per SIMD) with up to the whole LDS, tallies in LDS as for the small domains instead of one memory-side
+  // atomic per deposit (config 4 waited 57 % of its wave time behind them).  Flux runs only.
+  bool wide;
+  bool blockLite;  // wide plan, block walk, per-cell optics in global memory (trace_block_kernel<..., OPT_LDS = false>)
   int block;
   size_t lds;
 };
 
+bool blocks_worth_it(const mcbrat_ctx *c) {
+  if (!c->blockWalk || c->nDir > 0 || c->nBlocks <= 0) return false;
+  const size_t nvox = (size_t)c->nx * c->ny * c->nz;
+  return (size_t)c->nBlocks * 4 <= nvox || c->blockWalk == 2;  // (2: forced, for tests of heterogeneous media)
+}
+
 LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
   LaunchPlan L;
+  L.wide = false; L.blockLite = false;
   const size_t edges = sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3);
   const size_t tbl = sizeof(float) * (size_t)c->tblTotalFloats;
   const size_t slab = sizeof(long long) * slabStride + 16;
@@ -549,6 +582,26 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
   const size_t grid = nvox * 4 + (size_t)c->nc * nvox * (4 + 4) + (((size_t)c->nc * nvox + 1) & ~(size_t)1) * 2;
   L.gridLds = L.priv && c->gridLdsMode != 0 && edges + bg + slab + grid + (L.tblLds ? tbl : 0) <= kLdsBudget;
   L.lds = edges + bg + (L.priv ? slab : 0) + (L.gridLds ? grid : 0) + (L.tblLds ? tbl : 0);
+  // the wide plan: the slab did not fit beside another workgroup, but it fits a compute unit
+  const size_t cuLds = c->ldsPerCU > kStaticLds ? c->ldsPerCU - kStaticLds : 0;
+  if ((!L.priv || c->wideMode == 2) && c->privMode != 0 && c->wideMode != 0 && c->nDir == 0 && !L.brick && c->blockSize == 0 && edges + bg + slab <= cuLds) {
+    L.wide = true; L.priv = true; L.fly = false;
+    size_t need = edges + bg + slab;
+    L.tblLds = need + tbl <= cuLds;
+    if (L.tblLds) need += tbl;
+    L.gridLds = c->gridLdsMode == 1 && need + grid <= cuLds;
+    if (L.gridLds) need += grid;
+    L.lds = need;
+    L.block = 1024;
+    // block walk with the per-cell optics left in global memory: what a medium made of blocks whose grid does not fit still gets
+    if (!L.gridLds && blocks_worth_it(c) && c->gridLdsMode != 0) {
+      const BlockLds B = block_lds_layout(c->nx, c->ny, c->nz, c->nc, slabStride, c->nBlocks, (size_t)c->tblTotalFloats, false);
+      const BlockLds B0 = block_lds_layout(c->nx, c->ny, c->nz, c->nc, slabStride, c->nBlocks, 0, false);
+      if (B.total <= cuLds) { L.blockLite = true; L.tblLds = true; }
+      else if (B0.total <= cuLds) { L.blockLite = true; L.tblLds = false; }
+    }
+    return L;
+  }
   const size_t flyLds = per_layer_lds(c->nz, c->flyNbx * c->flyNby) - bg;
   L.fly = flight_wanted(c) && !L.gridLds && !L.brick && c->nDir == 0 && L.lds + flyLds <= kLdsBudget;
   if (L.fly) L.lds += flyLds;
@@ -571,7 +624,9 @@ inline unsigned long long units_per_batch(unsigned long long blocks, unsigned lo
   const double drainPhotons = 4000.0;
   unsigned long long best = 1;
   double bestCost = 1e300;
-  for (unsigned long long upb = 1; upb <= std::min<unsigned long long>(maxUpb, 64); ++upb) {
+  // (up to one unit per resident workgroup and a few rounds of them: a call of ONE large batch -- a wavelength's whole share
+  // of a broadband run -- must still reach every compute unit; the cap was 64, a quarter of the wide plan's 256 workgroups)
+  for (unsigned long long upb = 1; upb <= std::min<unsigned long long>(maxUpb, std::max<unsigned long long>(64, 4 * blocks)); ++upb) {
     const unsigned long long units = upb * (unsigned long long)nBatches;
     const unsigned long long rounds = (units + blocks - 1) / blocks;
     const double cost = (double)rounds * ((double)ppb / (double)upb + drainPhotons);
@@ -580,15 +635,15 @@ inline unsigned long long units_per_batch(unsigned long long blocks, unsigned lo
   return best;
 }
 
-template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN, bool EMIT, int SPEC = 0>
+template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN, bool EMIT, int SPEC = 0, bool TWO = false>
 int launch_trace_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
-  if (lds > c->ldsPerCU) return fail(c, "computeRadiativeTransfer: the grid's edge and layer tables do not fit the LDS of a compute unit.");
+  if (lds + kStaticLds > c->ldsPerCU && lds > kLdsBudget) return fail(c, "computeRadiativeTransfer: the grid's edge and layer tables do not fit the LDS of a compute unit.");
   if (lds > kLdsBudget)  // (very tall grids: the per-layer tables alone can pass the default limit of a workgroup)
-    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC>),
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC, TWO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int perCU = c->blocksPerCU;
   if (perCU <= 0) {
-    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC>, BLOCK, lds));
+    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC, TWO>, BLOCK, lds));
     perCU = std::max(1, std::min(perCU, 8));
   }
   unsigned long long blocks = (unsigned long long)perCU * c->numCUs;
@@ -604,7 +659,7 @@ int launch_trace_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   }
   const unsigned grid = (unsigned)std::max<unsigned long long>(1, blocks);
   p.ldsBytes = (unsigned)lds;
-  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC>), dim3(grid), dim3(BLOCK), lds, c->L().stream, p);
+  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC, TWO>), dim3(grid), dim3(BLOCK), lds, c->L().stream, p);
   HIP_OK(c, hipGetLastError());
   return 0;
 }
@@ -612,19 +667,30 @@ int launch_trace_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
 template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN = false>
 int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   // (the source kind is a template parameter: the emission launch code costs the solar instantiations registers)
-  if constexpr (BLOCK == 256 && PRIV == 0 && !BRICK && !DBG && !INTEN) {
-    // the large flux runs: dense grid in global memory, collision records (nc <= 2), layer-skipping walk, albedo
-    // surface -- with the walk's spacing flags decided at compile time too (SPEC, mcbrat_kernels.hip)
-    if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk && !p.zRegularWalk)
-      return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 3>(c, p, lds, nBatches)
-                             : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 3>(c, p, lds, nBatches);
-    if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk == p.zRegularWalk) {
-      if (p.xyRegularWalk)
-        return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 2>(c, p, lds, nBatches)
-                               : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 2>(c, p, lds, nBatches);
-      return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 1>(c, p, lds, nBatches)
-                             : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 1>(c, p, lds, nBatches);
+  if constexpr (BLOCK == 256 && PRIV == 0 && !BRICK && !INTEN) {
+    // two photons per lane (TWO, mcbrat_kernels.hip): flux runs on dense grids in global memory, solar source
+    const bool two = c->twoPhotons != 0 && c->srcKind == 0;
+    if constexpr (!DBG) {
+      // the large flux runs: dense grid in global memory, collision records (nc <= 2), layer-skipping walk, albedo
+      // surface -- with the walk's spacing flags decided at compile time too (SPEC, mcbrat_kernels.hip)
+      if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk && !p.zRegularWalk) {
+        if (two) return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 3, true>(c, p, lds, nBatches);
+        return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 3>(c, p, lds, nBatches)
+                               : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 3>(c, p, lds, nBatches);
+      }
+      if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk == p.zRegularWalk) {
+        if (p.xyRegularWalk) {
+          if (two) return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 2, true>(c, p, lds, nBatches);
+          return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 2>(c, p, lds, nBatches)
+                                 : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 2>(c, p, lds, nBatches);
+        }
+        if (two) return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 1, true>(c, p, lds, nBatches);
+        return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 1>(c, p, lds, nBatches)
+                               : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 1>(c, p, lds, nBatches);
+      }
     }
+    // the general instantiation (and the instrumented one, which counts events and records fates under the same schedule)
+    if (two) return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 0, true>(c, p, lds, nBatches);
   }
   return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false>(c, p, lds, nBatches)
                          : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true>(c, p, lds, nBatches);
@@ -666,19 +732,17 @@ int launch_trace_b(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, int nBatche
                   : launch_trace_t<BLOCK, false, 0, false, DBG>(c, p, L.lds, nBatches);
 }
 
-// The block walk applies where the face-by-face plan already keeps grid, tallies (and tables) in LDS, radiance is off,
-// and blocks are worth it: at least four cells per block on average (a medium that differs from cell to cell would
-// pay a position look-up at every face for nothing).
+// The block walk applies where the face-by-face plan already keeps grid, tallies (and tables) in LDS -- or, in the wide
+// plan, tallies and the cells' block numbers (blockLite) -- radiance is off, and blocks are worth it: at least four cells
+// per block on average (a medium that differs from cell to cell would pay a position look-up at every face for nothing).
 bool block_walk_applies(const mcbrat_ctx *c, const LaunchPlan &L) {
-  if (!c->blockWalk || !(L.priv && L.gridLds) || c->nDir > 0 || c->nBlocks <= 0) return false;
-  const size_t nvox = (size_t)c->nx * c->ny * c->nz;
-  return (size_t)c->nBlocks * 4 <= nvox || c->blockWalk == 2;  // (2: forced, for tests of heterogeneous media)
+  return blocks_worth_it(c) && ((L.priv && L.gridLds) || L.blockLite);
 }
 
-template <int BLOCK, bool TBL, bool DBG, bool EMIT, int SIMPLE>
+template <int BLOCK, bool TBL, bool DBG, bool EMIT, int SIMPLE, bool OPT = true>
 int launch_block_s(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
-  auto kernel = trace_block_kernel<BLOCK, TBL, DBG, EMIT, SIMPLE>;
-  if (lds > c->ldsPerCU) return fail(c, "computeRadiativeTransfer: the block-walk tables do not fit the LDS of a compute unit.");
+  auto kernel = trace_block_kernel<BLOCK, TBL, DBG, EMIT, SIMPLE, OPT>;
+  if (lds + 512 > c->ldsPerCU) return fail(c, "computeRadiativeTransfer: the block-walk tables do not fit the LDS of a compute unit.");
   if (lds > kLdsBudget)
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int perCU = c->blocksPerCU;
@@ -697,22 +761,32 @@ int launch_block_s(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   return 0;
 }
 
-template <int BLOCK, bool TBL, bool DBG, bool EMIT>
+template <int BLOCK, bool TBL, bool DBG, bool EMIT, bool OPT = true>
 int launch_block_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   // equally spaced axes, one component, no surface description: the instantiation with those decided at compile time
   const bool simple = c->xyRegular && c->zRegular && c->nc == 1 && c->surfNumX == 0;
-  if (simple && c->ny == 1 && !DBG) return launch_block_s<BLOCK, TBL, DBG, EMIT, 2>(c, p, lds, nBatches);  // an x-z problem
-  return simple ? launch_block_s<BLOCK, TBL, DBG, EMIT, 1>(c, p, lds, nBatches) : launch_block_s<BLOCK, TBL, DBG, EMIT, 0>(c, p, lds, nBatches);
+  if constexpr (OPT && BLOCK != 1024) {
+    if (simple && c->ny == 1 && !DBG) return launch_block_s<BLOCK, TBL, DBG, EMIT, 2, OPT>(c, p, lds, nBatches);  // an x-z problem
+  }
+  return simple ? launch_block_s<BLOCK, TBL, DBG, EMIT, 1, OPT>(c, p, lds, nBatches) : launch_block_s<BLOCK, TBL, DBG, EMIT, 0, OPT>(c, p, lds, nBatches);
 }
 
-template <int BLOCK, bool TBL, bool DBG>
+template <int BLOCK, bool TBL, bool DBG, bool OPT = true>
 int launch_block_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
-  return c->srcKind == 0 ? launch_block_e<BLOCK, TBL, DBG, false>(c, p, lds, nBatches) : launch_block_e<BLOCK, TBL, DBG, true>(c, p, lds, nBatches);
+  return c->srcKind == 0 ? launch_block_e<BLOCK, TBL, DBG, false, OPT>(c, p, lds, nBatches) : launch_block_e<BLOCK, TBL, DBG, true, OPT>(c, p, lds, nBatches);
 }
 
 int launch_block(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, bool debug, int nBatches) {
   const size_t lds = block_lds_layout(c->nx, c->ny, c->nz, c->nc, (size_t)p.slabStride, c->nBlocks,
-                                      L.tblLds ? (size_t)c->tblTotalFloats : 0).total;
+                                      L.tblLds ? (size_t)c->tblTotalFloats : 0, !L.blockLite).total;
+  if (L.wide) {  // one workgroup per compute unit: 1024 lanes (the instrumented instantiation: 512)
+    if (L.blockLite) {
+      if (debug) return L.tblLds ? launch_block_t<512, true, true, false>(c, p, lds, nBatches) : launch_block_t<512, false, true, false>(c, p, lds, nBatches);
+      return L.tblLds ? launch_block_t<1024, true, false, false>(c, p, lds, nBatches) : launch_block_t<1024, false, false, false>(c, p, lds, nBatches);
+    }
+    if (debug) return L.tblLds ? launch_block_t<512, true, true>(c, p, lds, nBatches) : launch_block_t<512, false, true>(c, p, lds, nBatches);
+    return L.tblLds ? launch_block_t<1024, true, false>(c, p, lds, nBatches) : launch_block_t<1024, false, false>(c, p, lds, nBatches);
+  }
   const int block = c->blockSize > 0 ? c->blockSize : 768;
   if (debug) return L.tblLds ? launch_block_t<512, true, true>(c, p, lds, nBatches) : launch_block_t<512, false, true>(c, p, lds, nBatches);
   if (block == 768) return L.tblLds ? launch_block_t<768, true, false>(c, p, lds, nBatches) : launch_block_t<768, false, false>(c, p, lds, nBatches);
@@ -735,13 +809,21 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   // instantiations that carry the bench workloads exist -- the step cloud's block walk and the 128x128x64 flux kernel
   if (block_walk_applies(c, L))
     return launch_block_s<768, true, false, false, 2>(c, p, block_lds_layout(c->nx, c->ny, c->nz, c->nc, (size_t)p.slabStride, c->nBlocks, (size_t)c->tblTotalFloats).total, nBatches);
-  if (debug) return launch_trace_e<256, false, 0, false, true, false, false, 0>(c, p, L.lds, nBatches);
+  if (debug) return c->twoPhotons ? launch_trace_e<256, false, 0, false, true, false, false, 0, true>(c, p, L.lds, nBatches)
+                                  : launch_trace_e<256, false, 0, false, true, false, false, 0>(c, p, L.lds, nBatches);
   if (!(p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0)) return fail(c, "development build: only the bench workloads' kernels exist");
   if (p.xyRegularWalk && !p.zRegularWalk) return launch_trace_e<256, false, 0, false, false, false, false, 3>(c, p, L.lds, nBatches);
-  if (!p.xyRegularWalk && !p.zRegularWalk) return launch_trace_e<256, false, 0, false, false, false, false, 1>(c, p, L.lds, nBatches);  // (the 128x128x64 bench fields)
+  if (!p.xyRegularWalk && !p.zRegularWalk)  // (the 128x128x64 bench fields)
+    return c->twoPhotons ? launch_trace_e<256, false, 0, false, false, false, false, 1, true>(c, p, L.lds, nBatches)
+                         : launch_trace_e<256, false, 0, false, false, false, false, 1>(c, p, L.lds, nBatches);
   return fail(c, "development build: only the bench workloads' kernels exist");
 #else
   if (block_walk_applies(c, L)) return launch_block(c, p, L, debug, nBatches);
+  if (L.wide) {  // one workgroup of 1024 lanes per compute unit, tallies (and what else fits) in its LDS; instrumented: 512 lanes
+    if (debug) return launch_trace_b<512, true>(c, p, L, nBatches);
+    if (L.gridLds) return L.tblLds ? launch_trace_t<1024, true, 2, false, false>(c, p, L.lds, nBatches) : launch_trace_t<1024, false, 2, false, false>(c, p, L.lds, nBatches);
+    return L.tblLds ? launch_trace_t<1024, true, 1, false, false>(c, p, L.lds, nBatches) : launch_trace_t<1024, false, 1, false, false>(c, p, L.lds, nBatches);
+  }
   // small domains (grid, tables and tallies in LDS): LDS holds two workgroups per CU, and two workgroups of 12 waves
   // (6 per SIMD, 80 VGPRs) beat two of 8 (4 per SIMD, no spills) by 10 % on the step cloud (640 and 896 lanes lose)
   // (radiance on LDS-resident domains keeps 512 lanes: 768 lanes at 80 VGPRs lose 20 % there)
@@ -819,6 +901,10 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (const char *e = getenv("MCBRAT_LAYER_SKIP")) c->layerSkip = atoi(e);
   if (const char *e = getenv("MCBRAT_BLOCK_WALK")) c->blockWalk = atoi(e);
   if (const char *e = getenv("MCBRAT_FLIGHT_MAX_DEPTH")) c->flightMaxDepth = atof(e);
+  if (const char *e = getenv("MCBRAT_WIDE")) c->wideDefault = c->wideMode = std::max(0, std::min(2, atoi(e)));
+  if (const char *e = getenv("MCBRAT_TWO_PHOTONS")) c->twoPhotons = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("MCBRAT_PAIR_THRESHOLD")) c->pairThreshold = std::max(1, std::min(65, atoi(e)));
+  if (const char *e = getenv("MCBRAT_SWAP_THRESHOLD")) c->swapThreshold = std::max(1, std::min(65, atoi(e)));
   if (const char *e = getenv("MCBRAT_JUMP_THRESHOLD")) c->jumpThreshold = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_CROSS_THRESHOLD")) c->crossThreshold = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_RAY_DEFER")) c->rayDefer = atoi(e);
@@ -830,6 +916,7 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (const char *e = getenv("MCBRAT_MAX_EVENTS")) c->maxEvents = (unsigned)std::max(16ll, atoll(e));
   if (const char *e = getenv("MCBRAT_MAX_EVENTS_NAN")) c->maxEventsNaN = (unsigned)std::max(16ll, atoll(e));
   if (const char *e = getenv("MCBRAT_TEST_LEGACY_TIES")) c->legacyTies = atoi(e);
+  if (const char *e = getenv("MCBRAT_TEST_RAY_MAX_LEN")) c->testRayMaxLen = (float)atof(e);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
     c->numCUs = prop.multiProcessorCount;
@@ -837,8 +924,8 @@ mcbrat_ctx *mcbrat_create(int device) {
   }
   if (init_lane(c, 0) || hipEventCreateWithFlags(&c->evExternal, hipEventDisableTiming) != hipSuccess ||
       dev_malloc((void **)&c->dEventCounters, 32 * sizeof(unsigned long long)) != hipSuccess ||
-      dev_malloc((void **)&c->dBad, sizeof(unsigned long long)) != hipSuccess ||
-      hipMemsetAsync(c->dBad, 0, sizeof(unsigned long long), c->lane[0].stream) != hipSuccess ||
+      dev_malloc((void **)&c->dBad, kBadWords * sizeof(unsigned long long)) != hipSuccess ||  // count, claim word, record of the first drop
+      hipMemsetAsync(c->dBad, 0, kBadWords * sizeof(unsigned long long), c->lane[0].stream) != hipSuccess ||
       hipStreamSynchronize(c->lane[0].stream) != hipSuccess ||
       hipHostMalloc((void **)&c->hBad, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void **)&c->hBadDev, c->hBad, 0) != hipSuccess) {
@@ -855,7 +942,7 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   (void)sync_all(c);
   void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF,
                   c->dEventCounters, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
-                  c->dBlockRec, c->dBlockOf, c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dExtWalk, c->dBgVal, c->dFlyRange, c->dSurfX, c->dSurfY, c->dSurfRefl,
+                  c->dBlockRec, c->dBlockOf, c->dBlockExt, c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dExtWalk, c->dBgVal, c->dFlyRange, c->dSurfX, c->dSurfY, c->dSurfRefl,
                   c->dBad, c->dFreqCdf, c->dFreqCounts, c->dDirData, c->dFwd, c->dFwdOrig};
   if (c->hBad) (void)hipHostFree(c->hBad);
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -869,6 +956,7 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   }
   for (auto &pr : c->eventPool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (c->evExternal) (void)hipEventDestroy(c->evExternal);
+  if (c->evChain) (void)hipEventDestroy(c->evChain);
   delete c;
 }
 
@@ -1063,7 +1151,7 @@ int mcbrat_reset_moments(mcbrat_ctx *c) {
   if (c->externalPending) { HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->evExternal, 0)); c->externalPending = false; }
   if (c->chainAfter) {
     if (c->chainSnapshot) HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->chainSnapshot, 0));
-    c->chainAfter = nullptr; c->chainSnapshot = nullptr;
+    c->chainAfter = false; c->chainSnapshot = nullptr;
   }
   HIP_OK(c, hipMemsetAsync(c->dMoments, 0, sizeof(double) * (8 + 2 * (size_t)moments_len(c)), c->L().stream));
   // stream-ordered before whatever the context enqueues next; readers synchronise (get_moments, report_results)
@@ -1222,8 +1310,15 @@ int mcbrat_chain_after(mcbrat_ctx *c, mcbrat_ctx *previous) {
   if (!c || !previous) return 1;
   if (c == previous) return fail(c, "chain_after: a context follows its own calls by itself.");
   if (c->device != previous->device) return fail(c, "chain_after: the two contexts are on different devices.");
-  c->chainAfter = previous;
-  c->chainSnapshot = previous->lastDone;  // (an event of `previous`, alive as long as it is; waited for before this context's next finish kernels)
+  (void)hipSetDevice(c->device);
+  c->chainAfter = false; c->chainSnapshot = nullptr;
+  if (!previous->lastDone) return 0;  // (nothing enqueued there yet: nothing to follow)
+  // "so far" is fixed NOW: an event of this context on the stream of `previous`'s latest call, whose finish chain follows all
+  // of its earlier ones.  `previous` may be destroyed or re-used afterwards; what is waited for does not change.
+  if (!c->evChain) HIP_OK(c, hipEventCreateWithFlags(&c->evChain, hipEventDisableTiming));
+  HIP_OK(c, hipEventRecord(c->evChain, previous->L().stream));
+  c->chainAfter = true;
+  c->chainSnapshot = c->evChain;
   return 0;
 }
 
@@ -1235,12 +1330,58 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   if (eventThreshold > 0) { c->eventThreshold = eventThreshold; c->autoTune = false; }
   if (eventThreshold == 0) { c->autoTune = true; c->tuned = false; }
   if (maxBatchesInFlight >= 0) c->maxBatchesInFlight = maxBatchesInFlight;
-  if (privateTallies >= 0) { c->privMode = privateTallies ? 1 : 0; c->gridLdsMode = privateTallies == 2 ? 0 : 1; }
+  // privateTallies: 0 global atomics; 1 the library's plan; 2 private tallies without the optical grid in LDS; 3 as 1 without the
+  // wide plan (a slab too large for a shared compute unit then tallies with global atomics); 4 the wide plan (one workgroup
+  // of 1024 lanes per compute unit) even where the shared plan would do; 5 as 4 with the per-cell optics left in global memory
+  if (privateTallies >= 0) {
+    if (privateTallies > 5) return fail(c, "set_tuning: privateTallies must be 0 ... 5");
+    c->privMode = privateTallies ? 1 : 0;
+    c->gridLdsMode = privateTallies == 2 ? 0 : (privateTallies == 5 ? 2 : 1);
+    c->wideMode = privateTallies == 3 ? 0 : (privateTallies >= 4 ? 2 : c->wideDefault);
+    c->tuned = false;
+  }
   if (blockSize == 0 || blockSize == 256 || blockSize == 512 || blockSize == 768) c->blockSize = blockSize;
   else if (blockSize > 0) return fail(c, "set_tuning: blockSize must be 0, 256, 512 or 768");
   if (launchThreshold > 0) { c->launchThreshold = launchThreshold; c->launchThresholdSet = true; }
   if (surfaceThreshold > 0) { c->surfaceThreshold = surfaceThreshold; c->surfaceThresholdSet = true; }
   if (brickLayout >= 0 && brickLayout <= 2) { if (brickLayout != c->brickMode) c->tuned = false; c->brickMode = brickLayout; }
+  return 0;
+}
+
+const char *mcbrat_first_drop(mcbrat_ctx *c) {
+  if (!c) return "";
+  (void)hipSetDevice(c->device);
+  c->dropText.clear();
+  unsigned long long h[kBadWords] = {0};
+  if (sync_all(c) || hipMemcpy(h, c->dBad, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return c->dropText.c_str();
+  if (h[0] == 0ull) return c->dropText.c_str();
+  static const char *kinds[] = {"?", "leg budget (maxEvents)", "leg budget of a photon with a NaN direction at full weight (maxEventsNaN)", "wave watchdog (no lane made progress)",
+                                "block crossings of one leg", "horizontal leg through vacuum in a block that spans both periodic axes", "view ray longer than the geometry allows"};
+  char buf[768];
+  int at = snprintf(buf, sizeof(buf), "%llu dropped; bounds that fired:", h[0]);
+  for (unsigned k = 1; k < 7; ++k)
+    if ((h[7] >> (k - 1)) & 1ull) at += snprintf(buf + at, sizeof(buf) - (size_t)at, " [%s]", kinds[k]);
+  if (h[1] != 0ull) {  // (the instrumented instantiations also record the first one)
+    const unsigned kind = (unsigned)(h[2] & 0xffu), kernel = (unsigned)((h[2] >> 8) & 0xffu), state = (unsigned)((h[2] >> 16) & 0xffffu);
+    snprintf(buf + at, sizeof(buf) - (size_t)at, "; first recorded: %s in %s, photon id %llu, %s %u, leg %u", kind < 7 ? kinds[kind] : "?",
+             kernel == 2 ? "trace_block_kernel" : "trace_kernel", h[3], kind == DROP_RAY ? "view direction" : "state", state, (unsigned)(h[2] >> 32));
+  } else {
+    snprintf(buf + at, sizeof(buf) - (size_t)at, "; no photon record (production kernels keep none: trace the same photons with mcbrat_trace_fates)");
+  }
+  c->dropText = buf;
+  return c->dropText.c_str();
+}
+
+int mcbrat_set_option(mcbrat_ctx *c, const char *name, int32_t value) {
+  if (!c) return 1;
+  if (!name) return fail(c, "set_option: no option name");
+  const std::string n(name);
+  if (n == "twoPhotons") { if ((value != 0) != (c->twoPhotons != 0)) c->tuned = false; c->twoPhotons = value ? 1 : 0; }
+  else if (n == "pairThreshold") c->pairThreshold = std::max(1, std::min(65, (int)value));
+  else if (n == "swapThreshold") c->swapThreshold = std::max(1, std::min(65, (int)value));
+  else if (n == "jumpThreshold") c->jumpThreshold = std::max(1, std::min(64, (int)value));
+  else if (n == "crossThreshold") c->crossThreshold = std::max(1, std::min(64, (int)value));
+  else return fail(c, "set_option: unknown option '" + n + "'");
   return 0;
 }
 
@@ -1322,7 +1463,8 @@ int mcbrat_get_walk_mode(const mcbrat_ctx *c) {
     const size_t ncol = (size_t)c->nx * c->ny;
     LaunchPlan L = plan_launch(c, 2 * ncol + ncol * c->nz);
     if (L.priv && L.brick) { L.priv = false; L.gridLds = false; }
-    m = (c->layerSkip ? 1 : 0) | (block_walk_applies(c, L) ? 2 : 0) | (L.fly ? 4 : 0) | (c->blockWalk ? 8 : 0);
+    m = (c->layerSkip ? 1 : 0) | (block_walk_applies(c, L) ? 2 : 0) | (L.fly ? 4 : 0) | (c->blockWalk ? 8 : 0) |
+        (L.wide ? 16 : 0) | (L.blockLite ? 32 : 0) | (L.priv ? 64 : 0);
   }
   return m;
 }
@@ -1415,7 +1557,7 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
     if (c->externalPending) { HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->evExternal, 0)); c->externalPending = false; }
     if (c->chainAfter) {  // contexts that share one moment array (one per wavelength): this finish chain after the other context's
       if (c->chainSnapshot) HIP_OK(c, hipStreamWaitEvent(c->L().stream, c->chainSnapshot, 0));
-      c->chainAfter = nullptr; c->chainSnapshot = nullptr;
+      c->chainAfter = false; c->chainSnapshot = nullptr;
     }
     FinishParams f;
     f.nx = c->nx; f.ny = c->ny; f.nz = c->nz; f.nBatches = nb; f.xyRegular = c->xyRegular; f.nDir = c->nDir; f.nc = c->nc; f.limitContrib = c->limitContrib;
@@ -1447,6 +1589,12 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   if (c->countersOn) {
     unsigned long long h[16];
     HIP_OK(c, hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost));
+    if (getenv("MCBRAT_DEBUG_TWO")) {  // development aid: the exchanges of the two-photons-per-lane kernel
+      unsigned long long t2[3];
+      HIP_OK(c, hipMemcpy(t2, c->dEventCounters + 25, sizeof(t2), hipMemcpyDeviceToHost));
+      fprintf(stderr, "two photons per lane: %llu exchanges of %.1f lanes, %llu second event phases (of %llu phases, %llu walk iterations)\n", t2[0],
+              t2[0] ? (double)t2[1] / (double)t2[0] : 0.0, t2[2], h[10], h[8]);
+    }
 #ifdef MCBRAT_STAMPS  // development aid: wave cycles per section of the tracing loop
     {
       unsigned long long st[16];

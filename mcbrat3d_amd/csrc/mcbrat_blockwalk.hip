@@ -45,7 +45,11 @@ __device__ __forceinline__ long long unwrapped_index(const double *e, int n, dou
 struct BlockLds {
   size_t slab, cursor, rec, ext, ssa, cum, pfi, blockOf, tbl, total;
 };
-__host__ __device__ inline BlockLds block_lds_layout(int nx, int ny, int nz, int nc, size_t slabLen, int nBlocks, size_t tblFloats) {
+// opticsLds = false (OPT_LDS = false below): the per-cell optics stay in global memory and LDS holds the extinction per
+// BLOCK instead of per cell -- 2 bytes per cell (its block) instead of 12, for domains whose tally slab takes most of a
+// compute unit's 160 KB (broadband 20 x 20 x 20: 70 KB of tallies + 36 KB of table + 16 KB of block numbers).
+__host__ __device__ inline BlockLds block_lds_layout(int nx, int ny, int nz, int nc, size_t slabLen, int nBlocks, size_t tblFloats,
+                                                      bool opticsLds = true) {
   BlockLds L;
   const size_t nvox = (size_t)nx * ny * nz;
   size_t o = sizeof(double) * (size_t)(nx + ny + nz + 3);
@@ -53,11 +57,12 @@ __host__ __device__ inline BlockLds block_lds_layout(int nx, int ny, int nz, int
   L.cursor = o; o += 16;
   o = (o + 15) & ~(size_t)15;
   L.rec = o; o += 16 * (size_t)nBlocks;
-  L.ext = o; o += 4 * nvox;
-  L.ssa = o; o += 4 * nvox * nc;
-  L.cum = o; o += nc > 1 ? 4 * nvox * nc : 0;  // (read only when there is more than one component)
-  L.pfi = o; o += 2 * ((nvox * nc + 1) & ~(size_t)1);
+  L.ext = o; o += opticsLds ? 4 * nvox : 4 * (((size_t)nBlocks + 3) & ~(size_t)3);
+  L.ssa = o; o += opticsLds ? 4 * nvox * nc : 0;
+  L.cum = o; o += (opticsLds && nc > 1) ? 4 * nvox * nc : 0;  // (read only when there is more than one component)
+  L.pfi = o; o += opticsLds ? 2 * ((nvox * nc + 1) & ~(size_t)1) : 0;
   L.blockOf = o; o += 2 * ((nvox + 1) & ~(size_t)1);
+  o = (o + 3) & ~(size_t)3;
   L.tbl = o; o += 4 * tblFloats;
   L.total = o;
   return L;
@@ -73,8 +78,11 @@ __host__ __device__ inline BlockLds block_lds_layout(int nx, int ny, int nz, int
 // problems): with a uniform surface nothing depends on the y position, so the y part of the leg origin, of the face
 // distances and of the cell look-ups is compiled out (the direction keeps its y component; the instrumented
 // instantiation keeps y, it counts the periodic y faces a leg crosses as the reference does).
-template <int BLOCK, bool TBL_LDS, bool DEBUG, bool EMIT, int SIMPLE>
-__global__ void __launch_bounds__(BLOCK, BLOCK > 512 ? BLOCK / 128 : MCBRAT_MIN_WAVES_PER_SIMD)
+// OPT_LDS = false: single-scattering albedo, cumulative fractions and phase-function index of a cell are read from global
+// memory at a collision (they sit in L2: a few tens of KB), the extinction comes from the cell's block; see block_lds_layout.
+// Workgroups of 1024 lanes are ONE per compute unit (they own most of its 160 KB of LDS): 4 waves per SIMD, 128 registers.
+template <int BLOCK, bool TBL_LDS, bool DEBUG, bool EMIT, int SIMPLE, bool OPT_LDS = true>
+__global__ void __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK > 512 ? BLOCK / 128 : MCBRAT_MIN_WAVES_PER_SIMD))
 trace_block_kernel(const DevParams p) {
   constexpr bool NOY = SIMPLE == 2 && !DEBUG;
   const bool xyRegular = SIMPLE != 0 ? true : p.xyRegular != 0;
@@ -92,11 +100,11 @@ trace_block_kernel(const DevParams p) {
   const int ncol = p.nx * p.ny;
   const int nvox = ncol * p.nz;
   const int slabLen = (int)p.slabStride;
-  const BlockLds lay = block_lds_layout(p.nx, p.ny, p.nz, nc, (size_t)slabLen, p.nBlocks, TBL_LDS ? (size_t)p.tblTotalFloats : 0);
+  const BlockLds lay = block_lds_layout(p.nx, p.ny, p.nz, nc, (size_t)slabLen, p.nBlocks, TBL_LDS ? (size_t)p.tblTotalFloats : 0, OPT_LDS);
   long long *s_slab = reinterpret_cast<long long *>(smem_raw + lay.slab);
   unsigned *s_cursor = reinterpret_cast<unsigned *>(smem_raw + lay.cursor);
   uint4 *s_blockRec = reinterpret_cast<uint4 *>(smem_raw + lay.rec);
-  float *s_ext = reinterpret_cast<float *>(smem_raw + lay.ext);
+  float *s_ext = reinterpret_cast<float *>(smem_raw + lay.ext);         // [nvox]; OPT_LDS = false: [nBlocks], the blocks' extinction
   float *s_ssa = reinterpret_cast<float *>(smem_raw + lay.ssa);         // [nc][nvox]
   float *s_cum = reinterpret_cast<float *>(smem_raw + lay.cum);         // [nc][nvox]
   uint16_t *s_pfi = reinterpret_cast<uint16_t *>(smem_raw + lay.pfi);   // [nc][nvox]
@@ -115,11 +123,21 @@ trace_block_kernel(const DevParams p) {
   for (int i = threadIdx.x; i < slabLen; i += BLOCK) s_slab[i] = 0;
   if (threadIdx.x == 0) s_cursor[0] = 0;
   for (int i = threadIdx.x; i < p.nBlocks; i += BLOCK) s_blockRec[i] = p.blockRec[i];
-  for (int i = threadIdx.x; i < nvox; i += BLOCK) { s_ext[i] = p.ext[i]; s_blockOf[i] = p.blockOf[i]; }
-  for (int i = threadIdx.x; i < nc * nvox; i += BLOCK) { s_ssa[i] = p.ssa[i]; s_pfi[i] = p.pfi[i]; }
-  if (nc > 1)
-    for (int i = threadIdx.x; i < nc * nvox; i += BLOCK) s_cum[i] = p.cum[i];
+  for (int i = threadIdx.x; i < nvox; i += BLOCK) s_blockOf[i] = p.blockOf[i];
+  if (OPT_LDS) {
+    for (int i = threadIdx.x; i < nvox; i += BLOCK) s_ext[i] = p.ext[i];
+    for (int i = threadIdx.x; i < nc * nvox; i += BLOCK) { s_ssa[i] = p.ssa[i]; s_pfi[i] = p.pfi[i]; }
+    if (nc > 1)
+      for (int i = threadIdx.x; i < nc * nvox; i += BLOCK) s_cum[i] = p.cum[i];
+  } else {
+    for (int i = threadIdx.x; i < p.nBlocks; i += BLOCK) s_ext[i] = p.blockExt[i];
+  }
   __syncthreads();
+  // optics of a cell (collisions) / extinction of a cell's block: LDS, or global memory and the block's value (OPT_LDS = false)
+  auto cumAt = [&](int i) -> float { if constexpr (OPT_LDS) return s_cum[i]; else return p.cum[i]; };
+  auto ssaAt = [&](int i) -> float { if constexpr (OPT_LDS) return s_ssa[i]; else return p.ssa[i]; };
+  auto pfiAt = [&](int i) -> int { if constexpr (OPT_LDS) return (int)s_pfi[i]; else return (int)p.pfi[i]; };
+  auto extOfCell = [&](int cell) -> float { if constexpr (OPT_LDS) return s_ext[cell]; else return s_ext[s_blockOf[cell]]; };
   const float *__restrict__ tbl = TBL_LDS ? s_tbl : p.tables;
   const int offY = p.nx + 1, offZ = p.nx + p.ny + 2;  // edge table offsets
   const double invDz = (double)p.nz / (p.zMax - p.z0);
@@ -195,14 +213,15 @@ trace_block_kernel(const DevParams p) {
   // TEST ONLY (DevParams::legacyTies): the tie handling from before the three fixes the soak runs led to, to show that the
   // bounds below end the kernel without them (tests/test_gpu_edge_cases.py).  Wave-uniform, read in the rare phases only.
   // (compiled into the instrumented instantiation only -- the one mcbrat_trace_fates runs: the production kernels carry none of it)
-  const bool legacyNoClamp = DEBUG && (p.legacyTies & 1) != 0, legacyMoveNaN = DEBUG && (p.legacyTies & 2) != 0,
-             legacyKeepSpans = DEBUG && (p.legacyTies & 4) != 0;
+  const bool legacyNoClamp = (DEBUG || kTestBounds) && (p.legacyTies & 1) != 0, legacyMoveNaN = (DEBUG || kTestBounds) && (p.legacyTies & 2) != 0,
+             legacyKeepSpans = (DEBUG || kTestBounds) && (p.legacyTies & 4) != 0;
   auto inRangeX = [&](int j, unsigned r) { return legacyNoClamp ? j : inRange(j, r); };  // clamp of a block crossing
   // Distances along the leg to the faces of the block that holds cell (ix, iy, iz); its extinction.
   auto enterBlock = [&](int ix, int iy, int iz) {
     const int cell = ix + p.nx * (iy + p.ny * iz);
-    const uint4 rec = s_blockRec[s_blockOf[cell]];
-    extCur = s_ext[cell];
+    const unsigned blk = s_blockOf[cell];
+    const uint4 rec = s_blockRec[blk];
+    if constexpr (OPT_LDS) extCur = s_ext[cell]; else extCur = s_ext[blk];
     rx = rec.x; rz = rec.z;
     if (!NOY) ry = rec.y;
     const int fx = dx >= 0.0f ? (int)(rx >> 16) : (int)(rx & 0xffffu);
@@ -223,12 +242,13 @@ trace_block_kernel(const DevParams p) {
   // one compare where a leg starts, the second lives in the crossing's own branch.
   unsigned nCrossLeg = 0;
   unsigned nBadLane = 0;  // photons this lane dropped at a loop bound; added to *p.bad when the kernel ends
-  const unsigned maxEvents = DEBUG ? p.maxEvents : kMaxEvents, maxEventsNaN = DEBUG ? p.maxEventsNaN : kMaxEventsNaN,
-                 watchdog = DEBUG ? p.watchdog : kWatchdog;
-#define MCBRAT_BW_DROP() do { \
+  const unsigned maxEvents = (DEBUG || kTestBounds) ? p.maxEvents : kMaxEvents, maxEventsNaN = (DEBUG || kTestBounds) ? p.maxEventsNaN : kMaxEventsNaN,
+                 watchdog = (DEBUG || kTestBounds) ? p.watchdog : kWatchdog;
+#define MCBRAT_BW_DROP(kind_) do { \
+    if constexpr (DEBUG || kTestBounds) record_first_drop(p.bad, (kind_), 2u, idLo, idHi, state, event);  /* (which bound, which photon) */ \
     if (DEBUG && p.fates) p.fates[(((unsigned long long)idHi << 32) | idLo) - p.firstPhoton] = mcbrat_fate{3, 0, 0, 0, nScat, nLegs, w}; \
     state = BW_DEAD; \
-    nBadLane++;  /* (added to *p.bad when the kernel ends: no atomic, no pointer in the loop) */ \
+    nBadLane = count_drop(nBadLane, (kind_));  /* (added to *p.bad when the kernel ends: no atomic, no pointer in the loop) */ \
   } while (0)
 #ifdef MCBRAT_STAMPS  // development aid (-DMCBRAT_STAMPS): wave cycles per section of the loop, reported with the event counters
   __shared__ unsigned long long s_tprev[BLOCK / 64], s_stamp[BLOCK / 64][9];
@@ -462,26 +482,26 @@ trace_block_kernel(const DevParams p) {
         int c = 0;  // component pick :759-760 (findIndex over [0, cumExt(:)]), uniform = slot Z of the leg's block
         if (nc > 1) {
           for (int k = 0; k < nc - 1; k++)
-            if (uZ >= s_cum[k * nvox + cell]) c = k + 1;
+            if (uZ >= cumAt(k * nvox + cell)) c = k + 1;
         }
-        float ssa = s_ssa[c * nvox + cell];
-        int pfEntry = s_pfi[c * nvox + cell];
+        float ssa = ssaAt(c * nvox + cell);
+        int pfEntry = pfiAt(c * nvox + cell);
         // A collision point within an ulp of a face of its block can be located next door -- harmless (the deposit and the
         // phase function of a cell an ulp away) unless next door is vacuum, where nothing collides: booked there the photon
         // would lose its whole weight (the host stores a single-scattering albedo of 0 where there is no extinction; the
         // soak run of the random box media caught one such photon in 8 million).  Then, and only then (clamping every
         // collision cost the step cloud 3 %), the cell is clamped to the block the lane is in.
-        if (ssa <= 0.0f && s_ext[cell] != extCur) {
+        if (ssa <= 0.0f && extOfCell(cell) != extCur) {
           ix = inRange(ix, rx); iz = inRange(iz, rz);
           if (!NOY) iy = inRange(iy, ry);
           cell = ix + p.nx * (iy + p.ny * iz);
           c = 0;
           if (nc > 1) {
             for (int k = 0; k < nc - 1; k++)
-              if (uZ >= s_cum[k * nvox + cell]) c = k + 1;
+              if (uZ >= cumAt(k * nvox + cell)) c = k + 1;
           }
-          ssa = s_ssa[c * nvox + cell];
-          pfEntry = s_pfi[c * nvox + cell];
+          ssa = ssaAt(c * nvox + cell);
+          pfEntry = pfiAt(c * nvox + cell);
         }
         if (DEBUG) countCrossings(px, py, iz);  // (after the fold of the look-ups above: px, py are the collision point)
         if (ssa < 1.0f) {  // absorption :765-771
@@ -545,7 +565,7 @@ trace_block_kernel(const DevParams p) {
       // (a photon is allowed maxEvents legs; one with a NaN direction -- see the collision above -- maxEventsNaN: where
       // omega0 = 1 its weight never falls and neither the reference nor the roulette would ever end it)
       if (needLeg && event >= maxEventsNaN) {  // (one compare on the hot path: maxEventsNaN <= maxEvents; the rule itself in the rare branch)
-        if (event >= maxEvents || !(dz == dz || w < 1.0f)) { needLeg = false; MCBRAT_BW_DROP(); }
+        if (event >= maxEvents || !(dz == dz || w < 1.0f)) { needLeg = false; MCBRAT_BW_DROP(event >= maxEvents ? DROP_LEGS : DROP_NAN_LEGS); }
       }
       if (needLeg) {
         event++;
@@ -609,7 +629,7 @@ trace_block_kernel(const DevParams p) {
         if (!legacyKeepSpans) spans = 0;
         enterBlock(jx, jy, jz);
         state = BW_MOVE;
-        if (++nCrossLeg > watchdog) MCBRAT_BW_DROP();  // (a leg that has crossed 2^20 blocks is going round in circles)
+        if (++nCrossLeg > watchdog) MCBRAT_BW_DROP(DROP_CROSSINGS);  // (a leg that has crossed 2^20 blocks is going round in circles)
       }
       STAMP(1);
       // wave-uniform exit: nothing alive and every lane has already been refused a new photon
@@ -640,7 +660,7 @@ trace_block_kernel(const DevParams p) {
         if (accNew > tau) {
           state = BW_COLLIDE;  // :1729-1738: the stop point is resolved at the head of the next iteration
         } else if (!(tmin < FLT_MAX)) {
-          MCBRAT_BW_DROP();    // no face ahead and nothing to collide with (a horizontal leg through vacuum): the reference walks for ever
+          MCBRAT_BW_DROP(DROP_VACUUM);    // no face ahead and nothing to collide with (a horizontal leg through vacuum): the reference walks for ever
         } else {
           acc = accNew;
           tcur = tmin;
@@ -664,7 +684,7 @@ trace_block_kernel(const DevParams p) {
     __syncthreads();
   }
 
-  if (nBadLane != 0u) atomicAdd(p.bad, (unsigned long long)nBadLane);
+  publish_drops(p.bad, nBadLane);
 #ifdef MCBRAT_STAMPS
   if (DEBUG && p.counters && lane == 0) for (int i = 0; i < 9; i++) atomicAdd(p.counters + 16 + i, s_stamp[threadIdx.x >> 6][i]);
 #endif

@@ -18,6 +18,40 @@ constexpr unsigned kMaxEvents = 1u << 24;     // legs per photon
 constexpr unsigned kMaxEventsNaN = 1u << 20;  // legs of a photon with a NaN direction that is still at full weight
 constexpr unsigned kWatchdog = 1u << 20;      // trace_kernel: event phases of a wave in which none of its lanes makes progress; block walk: block crossings of one leg
 
+// TEST ONLY build (-DMCBRAT_TEST_BOUNDS_IN_PRODUCTION, loaded through MCBRAT_LIB by tests/test_gpu_bounds.py): the PRODUCTION
+// instantiations take their loop bounds from DevParams too and honour the legacy tie switch, so that the code that keeps a
+// production kernel from hanging -- which differs from the instrumented instantiation's (compile-time constants, per-lane drop
+// counter) -- is itself driven into its bounds once.  The shipped library is built without it.
+#ifdef MCBRAT_TEST_BOUNDS_IN_PRODUCTION
+constexpr bool kTestBounds = true;
+#else
+constexpr bool kTestBounds = false;
+#endif
+
+// What the loop bounds dropped, beyond the count: so that one occurrence can be diagnosed from the run it happened in.
+// Layout of the device buffer behind DevParams::bad: [0] count, [1] claim word of the record (0 = none yet), [2..3] the record,
+// [7] which bounds have fired (bit kind - 1).
+//  * every kernel keeps the KINDS: per lane in the upper bits of its drop counter (a register it has anyway, no pointer and no
+//    atomic in the loop), OR-ed into [7] when the kernel ends;
+//  * the instrumented instantiations (and the test-only build of the production ones) also record the FIRST drop: kind, photon
+//    id, state, leg.  Not the production kernels: the record's pointer and atomic in the rare branch cost the 128x128x64 kernel
+//    5 % through register allocation (same-box A/B, profiles/r04_experiments.txt); photon ids are reproducible, so the same
+//    photons traced through mcbrat_trace_fates name the photon.
+enum : unsigned { DROP_LEGS = 1, DROP_NAN_LEGS = 2, DROP_WATCHDOG = 3, DROP_CROSSINGS = 4, DROP_VACUUM = 5, DROP_RAY = 6 };
+constexpr int kBadWords = 8;
+constexpr unsigned kBadCountMask = 0x03ffffffu;  // per-lane drop counter: count in the low 26 bits, kinds above
+__device__ __forceinline__ unsigned count_drop(unsigned nBadLane, unsigned kind) {
+  return (((nBadLane & kBadCountMask) + 1u) & kBadCountMask) | (nBadLane & ~kBadCountMask) | (1u << (25u + kind));
+}
+__device__ __forceinline__ void publish_drops(unsigned long long *bad, unsigned nBadLane) {  // when the kernel ends
+  if (nBadLane != 0u) { atomicAdd(bad, (unsigned long long)(nBadLane & kBadCountMask)); atomicOr(bad + 7, (unsigned long long)(nBadLane >> 26)); }
+}
+__device__ __forceinline__ void record_first_drop(unsigned long long *bad, unsigned kind, unsigned kernel, uint32_t idLo, uint32_t idHi, int state, uint32_t event) {
+  if (atomicCAS(bad + 1, 0ull, 1ull) != 0ull) return;  // (somebody else was first)
+  bad[2] = (unsigned long long)kind | ((unsigned long long)kernel << 8) | ((unsigned long long)(unsigned)state << 16) | ((unsigned long long)event << 32);
+  bad[3] = ((unsigned long long)idHi << 32) | idLo;
+}
+
 // States of a lane in the tracing loop.
 // ST_ENTER: a lane on the layer-skipping walk has reached a layer whose extinction varies from cell to cell and
 // waits for the event phase to bring its x/y state up to date.
@@ -77,6 +111,7 @@ struct DevParams {
   const uint4 *blockRec;          // [nBlocks] {x0 | x1 << 16, y0 | y1 << 16, z0 | z1 << 16, flags}: cell range [lo, hi) per axis;
                                   // flag bit 0 / 1: the block spans the whole periodic x / y axis (no face on it)
   const uint16_t *blockOf;        // [nvox] block of each cell
+  const float *blockExt;          // [nBlocks] extinction of each block (what LDS holds when the per-cell optics stay in global memory)
   int crossThreshold;             // lanes queued before block crossings are served
   // inverse phase-function tables (set_inverse_table)
   const float *tables;            // all components, concatenated, entry-major
@@ -121,6 +156,9 @@ struct DevParams {
   int launchThreshold;            // idle lanes queued before new photons are launched
   int surfaceThreshold;           // lanes queued before exits (top / surface) are served
   int jumpThreshold;              // lanes queued before transitions of the layer-skipping walk are served
+  // two photons per lane (trace_kernel<..., TWO>)
+  int pairThreshold;              // parked photons waiting for their collision that make the wave run another event phase at once
+  int swapThreshold;              // lanes whose photon has stopped while their parked one could walk that make the walk loop change them over
   // Termination guarantees.  The reference's walk marches by cell INDEX and drops a photon whose step
   // is not positive (opticalProperties.f95:1719-1722, counted in nBad, monteCarloRadiativeTransfer.f95:562-563); the kernels
   // here find cells from positions in places (block walk, clear-air flight, layer skipping), keep face distances in float,

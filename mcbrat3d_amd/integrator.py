@@ -222,14 +222,28 @@ class Integrator:
         if layerSkip >= 0 or blockWalk >= 0:
             self._check(self._lib.mcbrat_set_walk_options(self._ctx, int(layerSkip), int(blockWalk)))
 
+    def setOption(self, **options):
+        """Scheduling options by name (include/mcbrat.h: mcbrat_set_option), e.g. twoPhotons=0, pairThreshold=24."""
+        for name, value in options.items():
+            self._check(self._lib.mcbrat_set_option(self._ctx, name.encode(), int(value)))
+
     def walkMode(self):
         """The walk a flux run of the loaded domain uses (decided by the library's launch plan, mcbrat_get_walk_mode)."""
         m = int(self._lib.mcbrat_get_walk_mode(self._ctx))
-        return {"layerSkip": bool(m & 1), "blockWalk": bool(m & 2), "clearAirFlight": bool(m & 4)}
+        return {"layerSkip": bool(m & 1), "blockWalk": bool(m & 2), "clearAirFlight": bool(m & 4),
+                # tallies private to a workgroup in LDS; the wide plan: one workgroup of 1024 lanes per compute unit owns its LDS;
+                # the block walk with the per-cell optics left in global memory (extinction per block in LDS)
+                "privateTallies": bool(m & 64), "widePlan": bool(m & 16), "opticsInGlobalMemory": bool(m & 32)}
 
     def badPhotons(self):
         """Photons dropped by a loop bound of the kernels since this integrator was created (the reference's nBad, :562-563)."""
         return self.counters()["badPhotons"]
+
+    def firstDrop(self):
+        """What a loop bound dropped first since this integrator was created (which bound, photon id, state, cell, direction);
+        "" while badPhotons() is 0."""
+        msg = self._lib.mcbrat_first_drop(self._ctx)
+        return msg.decode() if msg else ""
 
     def eventThreshold(self):
         return int(self._lib.mcbrat_get_event_threshold(self._ctx))

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--bw", type=int, nargs="*", default=[-1], help="block walk (LDS-resident grids): -1 default, 0 off, 1 on")
     ap.add_argument("--n", type=int, default=128, help="landsat / radar: columns per side")
     ap.add_argument("--nz", type=int, default=64)
+    ap.add_argument("--opt", nargs="*", default=[], help="scheduling options by name, e.g. twoPhotons=0 pairThreshold=16,32 (comma: sweep)")
     ap.add_argument("--haze", type=float, default=100.0, help="case hazy: the Rayleigh component times this (optical depth 0.023 x haze)")
     a = ap.parse_args()
     import mcbrat3d_amd as M
@@ -60,9 +61,13 @@ def main():
     photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
     print("setup %.2fs" % (time.time() - t0), flush=True)
     import itertools
+    opt_names = [o.split("=")[0] for o in a.opt]
+    opt_values = [[int(v) for v in o.split("=")[1].split(",")] for o in a.opt]
     for bpc, priv, block, thr, lthr, sthr, brick, skip, bw in itertools.product(a.bpc, a.priv, a.block, a.thr, a.lthr, a.sthr, a.brick, a.skip, a.bw):
       for inflight in a.inflight:
-        if True:
+        for combo in itertools.product(*opt_values):
+            opts = dict(zip(opt_names, combo))
+            integ.setOption(**opts)
             integ.setTuning(blocksPerCU=bpc, eventThreshold=thr, privateTallies=priv, blockSize=block, launchThreshold=lthr, surfaceThreshold=sthr, brickLayout=brick, maxBatchesInFlight=inflight, layerSkip=skip, blockWalk=bw)
             rates = []
             for r in range(a.reps):
@@ -81,6 +86,7 @@ def main():
             res = integ.reportResults()
             if thr == 0:
                 print("   (event threshold chosen by the trial launches: %d)" % integ.eventThreshold())
+            print("opts=%s " % opts, end="")
             print("case=%s n=%d bw=%d skip=%d bpc=%d priv=%d block=%d thr=%d lthr=%d sthr=%d brick=%d inflight=%d ppb=%d nb=%d  wall %.3g ph/s  kernel %.3g ph/s  (means %.5f %.5f %.5f)" % (
                 a.case, a.n, bw, skip, bpc, priv, block, thr, lthr, sthr, brick, inflight, a.ppb, a.batches, max(r[0] for r in rates), max(r[1] for r in rates),
                 res["meanFluxUp"], res["meanFluxDown"], res["meanFluxAbsorbed"]), flush=True)

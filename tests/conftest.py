@@ -60,7 +60,8 @@ def _no_photon_dropped_by_a_loop_bound(request):
 
     def finalize(self):
         if getattr(self, "_ctx", None):
-            seen.append(int(self.counters()["badPhotons"]))
+            bad = int(self.counters()["badPhotons"])
+            seen.append((bad, self.firstDrop() if bad else ""))
         orig(self)
 
     I.Integrator.finalize = finalize
@@ -69,4 +70,4 @@ def _no_photon_dropped_by_a_loop_bound(request):
     finally:
         I.Integrator.finalize = orig
     if request.node.get_closest_marker("allow_bad_photons") is None:
-        assert all(b == 0 for b in seen), "photons dropped by a loop bound: %r" % (seen,)
+        assert all(b == 0 for b, _ in seen), "photons dropped by a loop bound: %r" % ([s for s in seen if s[0]],)

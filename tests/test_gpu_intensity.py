@@ -343,21 +343,36 @@ def test_random_domains_radiance_against_the_oracle(M, seed):
     fo = O.compute_rt(P, src, O.philox_rng(SEED, 0), n, want_fates=True)["fates"]
     flipped = np.flatnonzero((fg["fate"] != fo["fate"]) | (fg["ix"] != fo["ix"]) | (fg["iy"] != fo["iy"]) | (fg["iz"] != fo["iz"]) |
                              (fg["nScatter"] != fo["nScatter"]) | (np.abs(fg["weight"] - fo["weight"]) > 1e-6))
-    assert flipped.size <= 0.10 * n, (case["name"], flipped.size)  # (a medium of many small unlike cells is chaotic: soak seed 70 of 400 flips 7 %)
-    for i in flipped:
+    # (the identity tests accept 1.5 % flipped histories; a medium of many small unlike cells is chaotic and flips more: those
+    # seeds are listed, with what they were seen to flip, instead of one wide bound for all)
+    assert flipped.size <= CHAOTIC_SEEDS.get(seed, 0.015) * n, (case["name"], seed, flipped.size)
+    diffs = np.zeros((flipped.size, ndir))  # per flipped photon and direction: what it adds to the domain mean, product minus oracle
+    for k, i in enumerate(flipped):
         integ.resetMoments()
         integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED, firstPhotonId=int(i)), photons, 1)
-        g -= integ.reportResults()["intensity"].astype(np.float64) / n
+        gi = integ.reportResults()["intensity"].astype(np.float64) / n
         one = O.compute_radiative_transfer_intensity(P, src, O.philox_rng(SEED, int(i)), 1, I)
-        r = r - one["intensity"].reshape(-1, ny, nx).transpose(2, 1, 0).astype(np.float64) / n
+        ri = one["intensity"].reshape(-1, ny, nx).transpose(2, 1, 0).astype(np.float64) / n
+        g -= gi
+        r = r - ri
+        diffs[k] = gi.mean(axis=(0, 1)) - ri.mean(axis=(0, 1))
     integ.finalize()
     for d in range(ndir):
         level = abs(float(ref["meanIntensity"][d])) + 1e-4
         assert abs(g[:, :, d].mean() - r[:, :, d].mean()) < 2e-2 * level, (case["name"], d, flipped.size, g[:, :, d].mean(), r[:, :, d].mean())
         assert np.mean(np.abs(g[:, :, d] - r[:, :, d])) < 2e-2 * (float(np.mean(np.abs(r[:, :, d]))) + 1e-4), \
             (case["name"], d, flipped.size, np.mean(np.abs(g[:, :, d] - r[:, :, d])) / (float(np.mean(np.abs(r[:, :, d]))) + 1e-4))
-    # (and with every photon in: the flipped ones are a couple of percent of the photons, so are their radiances)
-    assert np.allclose(got["meanIntensity"], ref["meanIntensity"], rtol=0.25, atol=5e-4), (case["name"], got["meanIntensity"], ref["meanIntensity"])
+        # The flipped histories themselves: two different samples of the same photon's possible fates, so what they add to a
+        # direction mean may differ photon by photon but must not LEAN -- the sum of the differences against the root of the
+        # sum of their squares, 4 sigma (a bias confined to tie handling under grazing views would show here; the flat 25 %
+        # bound on the whole mean this replaces would have let it through).
+        sd = float(np.sqrt((diffs[:, d] ** 2).sum()))
+        assert abs(float(diffs[:, d].sum())) <= 4.0 * sd + 1e-3 * level, (case["name"], d, flipped.size, float(diffs[:, d].sum()), sd)
+
+
+# seeds of random_radiance_case whose medium is chaotic (many small unlike cells): share of the histories seen to flip between
+# product and oracle, as a bound with some room (soak runs; every other seed must stay within the 1.5 % of the identity tests)
+CHAOTIC_SEEDS = {70: 0.10}
 
 
 def random_radiance_case(seed):

@@ -22,12 +22,17 @@ def M():
 FUZZ = int(os.environ.get("MCBRAT_FLIGHT_FUZZ", "12"))  # seeds of the random differential test (raise it for a soak run)
 
 
+OPTIONS = ("twoPhotons", "pairThreshold", "swapThreshold")  # by name (mcbrat_set_option), the rest through setTuning
+
+
 def _run(M, case, mu0, phi0, rr, walk, tuning, n=12000):
     from mcbrat3d_amd.integrator import new_RandomNumberSequence
     dom = cases.product_domain(case)
     integ = M.new_Integrator(dom)
     integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=rr)
-    integ.setTuning(**walk, **tuning)
+    both = {**walk, **tuning}
+    integ.setTuning(**{k: v for k, v in both.items() if k not in OPTIONS})
+    integ.setOption(**{k: v for k, v in both.items() if k in OPTIONS})
     photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 9)
     fates = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
     integ.resetMoments()
@@ -45,11 +50,26 @@ def test_random_tunings_give_the_same_histories(M, seed):
     sched = dict(eventThreshold=int(rng.choice([1, 4, 16, 40, 64])), blockSize=int(rng.choice([0, 256, 512])),
                  launchThreshold=int(rng.choice([1, 8, 32])), surfaceThreshold=int(rng.choice([1, 12, 32])),
                  blocksPerCU=int(rng.choice([0, 1, 3])), maxBatchesInFlight=int(rng.choice([0, 1, 2])))
-    layout = dict(privateTallies=int(rng.integers(0, 2)), brickLayout=int(rng.integers(0, 2)))
+    # privateTallies 4 / 5: the wide plan -- one workgroup of 1024 lanes per compute unit with the tallies in its LDS, the
+    # optical grid beside them (4) or left in global memory (5: for the block walk, extinction per block in LDS) -- which
+    # the library chooses by itself only for tally slabs too large to share a compute unit (config 4's 70 KB)
+    # two photons per lane (trace_kernel<..., TWO>: tallies in global memory, dense grid) against the one-photon kernel, with
+    # random thresholds of the exchange (65: never)
+    two = dict(twoPhotons=int(rng.integers(0, 2)), pairThreshold=int(rng.choice([1, 8, 16, 40, 65])), swapThreshold=int(rng.choice([1, 8, 24, 65])))
+    layout = dict(privateTallies=int(rng.choice([0, 1, 4, 5])), brickLayout=int(rng.integers(0, 2)))
+    if layout["privateTallies"] >= 4:
+        layout.update(blockSize=0, brickLayout=0)
     for name, walk, base_tuning, tuning in (
-            ("face by face", dict(layerSkip=0, blockWalk=0), dict(eventThreshold=16, privateTallies=0, brickLayout=0), dict(**sched, **layout)),
-            ("layers + flight", dict(layerSkip=3, blockWalk=0, privateTallies=0, brickLayout=0), dict(eventThreshold=16), sched),
-            ("block walk", dict(blockWalk=2), dict(eventThreshold=16), {k: v for k, v in sched.items() if k != "blockSize"})):
+            ("face by face", dict(layerSkip=0, blockWalk=0), dict(eventThreshold=16, privateTallies=0, brickLayout=0, twoPhotons=0), {**sched, **layout, **two}),
+            ("layers + flight", dict(layerSkip=3, blockWalk=0, privateTallies=0, brickLayout=0), dict(eventThreshold=16, twoPhotons=0), {**sched, **two}),
+            ("layers + flight, two photons per lane", dict(layerSkip=3, blockWalk=0, privateTallies=0, brickLayout=0), dict(eventThreshold=16, twoPhotons=0),
+             {**{k: v for k, v in sched.items() if k != "blockSize"}, **two, "twoPhotons": 1}),
+            # (layerSkip = 2: the layers without the clear-air flight, which the wide plan does not carry; privateTallies = 5:
+            # with the grid in LDS too -- 4 -- the walk is the face-by-face one, the first row's)
+            ("layers, wide plan", dict(layerSkip=2, blockWalk=0, brickLayout=0), dict(eventThreshold=16, privateTallies=0),
+             {**{k: v for k, v in sched.items() if k != "blockSize"}, "privateTallies": 5}),
+            ("block walk", dict(blockWalk=2), dict(eventThreshold=16),
+             {**{k: v for k, v in sched.items() if k != "blockSize"}, "privateTallies": int(rng.choice([1, 4, 5]))})):
         base = _run(M, case, mu0, phi0, rr, walk, base_tuning)
         got = _run(M, case, mu0, phi0, rr, walk, tuning)
         for f in base[0].dtype.names:
@@ -65,7 +85,7 @@ def _run_thermal(M, case, rr, walk, tuning, n=12000):
     M.emission_weighting(dom, w, case["sfc_temp"])
     integ = M.new_Integrator(dom)
     integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=rr, LW_flag=1.0)
-    integ.setTuning(**walk, **tuning)
+    integ.setTuning(**{**walk, **tuning})
     photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 9)
     fates = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
     integ.resetMoments()
@@ -89,10 +109,14 @@ def test_random_tunings_give_the_same_histories_thermal_source(M, seed):
     case["lambda_um"] = float(rng.uniform(6.0, 14.0))
     sched = dict(eventThreshold=int(rng.choice([1, 4, 16, 40, 64])), launchThreshold=int(rng.choice([1, 8, 48])),
                  surfaceThreshold=int(rng.choice([1, 12, 32])), maxBatchesInFlight=int(rng.choice([0, 1, 2])))
-    for name, walk in (("face by face", dict(layerSkip=0, blockWalk=0, privateTallies=0)), ("layers", dict(layerSkip=3, blockWalk=0, privateTallies=0)),
-                       ("block walk", dict(blockWalk=2))):
+    wide = dict(privateTallies=int(rng.choice([4, 5])))  # the wide plan (config 4's), see above
+    for name, walk, plans in (("face by face", dict(layerSkip=0, blockWalk=0, privateTallies=0), [wide]),
+                              ("layers + flight", dict(layerSkip=3, blockWalk=0, privateTallies=0), []),  # (the wide plan carries no flight)
+                              # (privateTallies = 5: with the grid in LDS too -- 4 -- the walk is the face-by-face one)
+                              ("layers", dict(layerSkip=2, blockWalk=0, privateTallies=0), [dict(privateTallies=5)]),
+                              ("block walk", dict(blockWalk=2), [wide])):
         base = _run_thermal(M, case, rr, walk, {})                                                # the thermal source's own defaults
-        for tuning in (dict(eventThreshold=16, launchThreshold=8), sched):                       # the solar source's; a random choice
+        for tuning in [dict(eventThreshold=16, launchThreshold=8), sched] + [{**sched, **w} for w in plans]:  # the solar source's; a random choice; the same in the wide plan
             got = _run_thermal(M, case, rr, walk, tuning)
             for f in base[0].dtype.names:
                 assert np.array_equal(got[0][f], base[0][f], equal_nan=True), (name, f, tuning)

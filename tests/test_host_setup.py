@@ -30,7 +30,7 @@ def test_abi_exports_every_declared_symbol(M):
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mcbrat_abi_version() == 2
+    assert L.mcbrat_abi_version() == 3
 
 
 def test_no_cpu_fallback(M):
