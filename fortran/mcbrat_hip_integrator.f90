@@ -460,7 +460,7 @@ contains
     integer, intent(out) :: ierr
     ierr = mcbrat_set_walk_options(this%ctx, merge(1_c_int32_t, 0_c_int32_t, layerSkip), merge(1_c_int32_t, 0_c_int32_t, blockWalk))
   end subroutine setWalkOptions
-  ! Scheduling options by name (include/mcbrat.h: mcbrat_set_option), e.g. setOption(this, "twoPhotons", 0, ierr); none of them
+  ! Scheduling options by name (include/mcbrat.h: mcbrat_set_option), e.g. setOption(this, "jumpThreshold", 16, ierr); none of them
   ! changes a result.  The reference has no counterpart.
   subroutine setOption(this, name, value, ierr)
     type(integrator), intent(inout) :: this

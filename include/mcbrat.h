@@ -222,10 +222,6 @@ int mcbrat_set_tuning(mcbrat_ctx *ctx, int32_t blocksPerCU, int32_t eventThresho
 
 /* Scheduling options by name (none of them changes a result: the same photons, the same arithmetic per photon, integer
  * tallies -- tests/test_gpu_tunings.py holds random choices against the defaults bit for bit).  ABI 3.
- *   "twoPhotons"    1 (default) / 0: large flux runs (dense grid in global memory, solar source) keep TWO photons per lane in
- *                   registers, so that a lane whose photon has stopped walking goes on with its other one (trace_kernel<..., TWO>)
- *   "pairThreshold" parked photons waiting for their collision that make a wave run another event phase at once (65: never)
- *   "swapThreshold" lanes whose photon has stopped while their parked one could walk that make the walk loop change them over
  *   "jumpThreshold", "crossThreshold"  lanes queued before transitions of the layer-skipping walk / block crossings are served
  * The reference has no counterpart (its loop is one photon at a time, monteCarloRadiativeTransfer.f95:463-466). */
 int mcbrat_set_option(mcbrat_ctx *ctx, const char *name, int32_t value);

@@ -78,10 +78,6 @@ struct mcbrat_ctx {
   int nBlocks = 0;
   int crossThreshold = 8;      // MCBRAT_CROSS_THRESHOLD
   int jumpThreshold = 8;       // MCBRAT_JUMP_THRESHOLD
-  // two photons per lane (trace_kernel<..., TWO>; large flux runs: dense grid in global memory, solar source)
-  int twoPhotons = 0;          // (off: measured 38 % slower) MCBRAT_TWO_PHOTONS / mcbrat_set_option("twoPhotons")
-  int pairThreshold = 16;      // MCBRAT_PAIR_THRESHOLD / "pairThreshold"
-  int swapThreshold = 24;      // MCBRAT_SWAP_THRESHOLD / "swapThreshold"
   float *dExtB = nullptr, *dCumB = nullptr, *dSsaB = nullptr, *dBgExt = nullptr, *dBgCum = nullptr, *dBgSsa = nullptr;
   uint16_t *dPfiB = nullptr, *dBgPfi = nullptr;
   int nbx = 0, nby = 0, nbz = 0;
@@ -509,8 +505,6 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.nBlocks = c->nBlocks; p.blockRec = reinterpret_cast<const uint4 *>(c->dBlockRec); p.blockOf = c->dBlockOf; p.blockExt = c->dBlockExt;
   p.crossThreshold = std::max(1, std::min(64, c->crossThreshold));
   p.jumpThreshold = std::max(1, std::min(64, c->jumpThreshold));
-  p.pairThreshold = std::max(1, std::min(65, c->pairThreshold));  // (65: never)
-  p.swapThreshold = std::max(1, std::min(65, c->swapThreshold));
   p.bad = c->dBad;
   p.maxEvents = c->maxEvents; p.maxEventsNaN = std::min(c->maxEventsNaN, c->maxEvents); p.watchdog = c->watchdog;  // (the kernels test the smaller one first)
   p.legacyTies = c->legacyTies;
@@ -635,15 +629,15 @@ inline unsigned long long units_per_batch(unsigned long long blocks, unsigned lo
   return best;
 }
 
-template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN, bool EMIT, int SPEC = 0, bool TWO = false>
+template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN, bool EMIT, int SPEC = 0>
 int launch_trace_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   if (lds + kStaticLds > c->ldsPerCU && lds > kLdsBudget) return fail(c, "computeRadiativeTransfer: the grid's edge and layer tables do not fit the LDS of a compute unit.");
   if (lds > kLdsBudget)  // (very tall grids: the per-layer tables alone can pass the default limit of a workgroup)
-    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC, TWO>),
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int perCU = c->blocksPerCU;
   if (perCU <= 0) {
-    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC, TWO>, BLOCK, lds));
+    HIP_OK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC>, BLOCK, lds));
     perCU = std::max(1, std::min(perCU, 8));
   }
   unsigned long long blocks = (unsigned long long)perCU * c->numCUs;
@@ -659,7 +653,7 @@ int launch_trace_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   }
   const unsigned grid = (unsigned)std::max<unsigned long long>(1, blocks);
   p.ldsBytes = (unsigned)lds;
-  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC, TWO>), dim3(grid), dim3(BLOCK), lds, c->L().stream, p);
+  hipLaunchKernelGGL((trace_kernel<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, EMIT, SPEC>), dim3(grid), dim3(BLOCK), lds, c->L().stream, p);
   HIP_OK(c, hipGetLastError());
   return 0;
 }
@@ -667,30 +661,19 @@ int launch_trace_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
 template <int BLOCK, bool TBL, int PRIV, bool BRICK, bool DBG, bool INTEN = false>
 int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   // (the source kind is a template parameter: the emission launch code costs the solar instantiations registers)
-  if constexpr (BLOCK == 256 && PRIV == 0 && !BRICK && !INTEN) {
-    // two photons per lane (TWO, mcbrat_kernels.hip): flux runs on dense grids in global memory, solar source
-    const bool two = c->twoPhotons != 0 && c->srcKind == 0;
-    if constexpr (!DBG) {
-      // the large flux runs: dense grid in global memory, collision records (nc <= 2), layer-skipping walk, albedo
-      // surface -- with the walk's spacing flags decided at compile time too (SPEC, mcbrat_kernels.hip)
-      if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk && !p.zRegularWalk) {
-        if (two) return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 3, true>(c, p, lds, nBatches);
-        return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 3>(c, p, lds, nBatches)
-                               : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 3>(c, p, lds, nBatches);
-      }
-      if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk == p.zRegularWalk) {
-        if (p.xyRegularWalk) {
-          if (two) return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 2, true>(c, p, lds, nBatches);
-          return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 2>(c, p, lds, nBatches)
-                                 : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 2>(c, p, lds, nBatches);
-        }
-        if (two) return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 1, true>(c, p, lds, nBatches);
-        return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 1>(c, p, lds, nBatches)
-                               : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 1>(c, p, lds, nBatches);
-      }
+  if constexpr (BLOCK == 256 && PRIV == 0 && !BRICK && !DBG && !INTEN) {
+    // the large flux runs: dense grid in global memory, collision records (nc <= 2), layer-skipping walk, albedo
+    // surface -- with the walk's spacing flags decided at compile time too (SPEC, mcbrat_kernels.hip)
+    if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk && !p.zRegularWalk)
+      return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 3>(c, p, lds, nBatches)
+                             : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 3>(c, p, lds, nBatches);
+    if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk == p.zRegularWalk) {
+      if (p.xyRegularWalk)
+        return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 2>(c, p, lds, nBatches)
+                               : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 2>(c, p, lds, nBatches);
+      return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 1>(c, p, lds, nBatches)
+                             : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 1>(c, p, lds, nBatches);
     }
-    // the general instantiation (and the instrumented one, which counts events and records fates under the same schedule)
-    if (two) return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 0, true>(c, p, lds, nBatches);
   }
   return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false>(c, p, lds, nBatches)
                          : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true>(c, p, lds, nBatches);
@@ -809,13 +792,10 @@ int launch_trace(mcbrat_ctx *c, DevParams &p, bool debug, int nBatches) {
   // instantiations that carry the bench workloads exist -- the step cloud's block walk and the 128x128x64 flux kernel
   if (block_walk_applies(c, L))
     return launch_block_s<768, true, false, false, 2>(c, p, block_lds_layout(c->nx, c->ny, c->nz, c->nc, (size_t)p.slabStride, c->nBlocks, (size_t)c->tblTotalFloats).total, nBatches);
-  if (debug) return c->twoPhotons ? launch_trace_e<256, false, 0, false, true, false, false, 0, true>(c, p, L.lds, nBatches)
-                                  : launch_trace_e<256, false, 0, false, true, false, false, 0>(c, p, L.lds, nBatches);
+  if (debug) return launch_trace_e<256, false, 0, false, true, false, false, 0>(c, p, L.lds, nBatches);
   if (!(p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0)) return fail(c, "development build: only the bench workloads' kernels exist");
   if (p.xyRegularWalk && !p.zRegularWalk) return launch_trace_e<256, false, 0, false, false, false, false, 3>(c, p, L.lds, nBatches);
-  if (!p.xyRegularWalk && !p.zRegularWalk)  // (the 128x128x64 bench fields)
-    return c->twoPhotons ? launch_trace_e<256, false, 0, false, false, false, false, 1, true>(c, p, L.lds, nBatches)
-                         : launch_trace_e<256, false, 0, false, false, false, false, 1>(c, p, L.lds, nBatches);
+  if (!p.xyRegularWalk && !p.zRegularWalk) return launch_trace_e<256, false, 0, false, false, false, false, 1>(c, p, L.lds, nBatches);  // (the 128x128x64 bench fields)
   return fail(c, "development build: only the bench workloads' kernels exist");
 #else
   if (block_walk_applies(c, L)) return launch_block(c, p, L, debug, nBatches);
@@ -902,9 +882,6 @@ mcbrat_ctx *mcbrat_create(int device) {
   if (const char *e = getenv("MCBRAT_BLOCK_WALK")) c->blockWalk = atoi(e);
   if (const char *e = getenv("MCBRAT_FLIGHT_MAX_DEPTH")) c->flightMaxDepth = atof(e);
   if (const char *e = getenv("MCBRAT_WIDE")) c->wideDefault = c->wideMode = std::max(0, std::min(2, atoi(e)));
-  if (const char *e = getenv("MCBRAT_TWO_PHOTONS")) c->twoPhotons = atoi(e) ? 1 : 0;
-  if (const char *e = getenv("MCBRAT_PAIR_THRESHOLD")) c->pairThreshold = std::max(1, std::min(65, atoi(e)));
-  if (const char *e = getenv("MCBRAT_SWAP_THRESHOLD")) c->swapThreshold = std::max(1, std::min(65, atoi(e)));
   if (const char *e = getenv("MCBRAT_JUMP_THRESHOLD")) c->jumpThreshold = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_CROSS_THRESHOLD")) c->crossThreshold = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("MCBRAT_RAY_DEFER")) c->rayDefer = atoi(e);
@@ -1376,10 +1353,7 @@ int mcbrat_set_option(mcbrat_ctx *c, const char *name, int32_t value) {
   if (!c) return 1;
   if (!name) return fail(c, "set_option: no option name");
   const std::string n(name);
-  if (n == "twoPhotons") { if ((value != 0) != (c->twoPhotons != 0)) c->tuned = false; c->twoPhotons = value ? 1 : 0; }
-  else if (n == "pairThreshold") c->pairThreshold = std::max(1, std::min(65, (int)value));
-  else if (n == "swapThreshold") c->swapThreshold = std::max(1, std::min(65, (int)value));
-  else if (n == "jumpThreshold") c->jumpThreshold = std::max(1, std::min(64, (int)value));
+  if (n == "jumpThreshold") c->jumpThreshold = std::max(1, std::min(64, (int)value));
   else if (n == "crossThreshold") c->crossThreshold = std::max(1, std::min(64, (int)value));
   else return fail(c, "set_option: unknown option '" + n + "'");
   return 0;
@@ -1589,12 +1563,6 @@ int mcbrat_compute_radiative_transfer(mcbrat_ctx *c, uint64_t seed, uint64_t fir
   if (c->countersOn) {
     unsigned long long h[16];
     HIP_OK(c, hipMemcpy(h, c->dEventCounters, sizeof(h), hipMemcpyDeviceToHost));
-    if (getenv("MCBRAT_DEBUG_TWO")) {  // development aid: the exchanges of the two-photons-per-lane kernel
-      unsigned long long t2[3];
-      HIP_OK(c, hipMemcpy(t2, c->dEventCounters + 25, sizeof(t2), hipMemcpyDeviceToHost));
-      fprintf(stderr, "two photons per lane: %llu exchanges of %.1f lanes, %llu second event phases (of %llu phases, %llu walk iterations)\n", t2[0],
-              t2[0] ? (double)t2[1] / (double)t2[0] : 0.0, t2[2], h[10], h[8]);
-    }
 #ifdef MCBRAT_STAMPS  // development aid: wave cycles per section of the tracing loop
     {
       unsigned long long st[16];

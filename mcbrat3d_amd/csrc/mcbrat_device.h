@@ -156,9 +156,6 @@ struct DevParams {
   int launchThreshold;            // idle lanes queued before new photons are launched
   int surfaceThreshold;           // lanes queued before exits (top / surface) are served
   int jumpThreshold;              // lanes queued before transitions of the layer-skipping walk are served
-  // two photons per lane (trace_kernel<..., TWO>)
-  int pairThreshold;              // parked photons waiting for their collision that make the wave run another event phase at once
-  int swapThreshold;              // lanes whose photon has stopped while their parked one could walk that make the walk loop change them over
   // Termination guarantees.  The reference's walk marches by cell INDEX and drops a photon whose step
   // is not positive (opticalProperties.f95:1719-1722, counted in nBad, monteCarloRadiativeTransfer.f95:562-563); the kernels
   // here find cells from positions in places (block walk, clear-air flight, layer skipping), keep face distances in float,

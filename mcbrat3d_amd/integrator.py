@@ -223,7 +223,7 @@ class Integrator:
             self._check(self._lib.mcbrat_set_walk_options(self._ctx, int(layerSkip), int(blockWalk)))
 
     def setOption(self, **options):
-        """Scheduling options by name (include/mcbrat.h: mcbrat_set_option), e.g. twoPhotons=0, pairThreshold=24."""
+        """Scheduling options by name (include/mcbrat.h: mcbrat_set_option), e.g. jumpThreshold=16."""
         for name, value in options.items():
             self._check(self._lib.mcbrat_set_option(self._ctx, name.encode(), int(value)))
 

@@ -29,7 +29,9 @@ for f in files:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
             tracing = ("trace_kernel" in k or "trace_block_kernel" in k)
-            debug = tracing and k.split("(mcbrat::DevParams")[0].rstrip(">").rstrip().endswith("true") and "trace_block_kernel" in k
+            # the instrumented instantiation (DEBUG: third template argument of trace_block_kernel, fifth of trace_kernel) is not the product
+            targs = [a.strip() for a in k.split("<", 1)[1].split(">(")[0].split(",")] if tracing and "<" in k else []
+            debug = tracing and len(targs) > 4 and (targs[2] if "trace_block_kernel" in k else targs[4]) == "true"
             short = "trace_kernel" if tracing and not debug else k.split("(")[0][-40:]
             acc[short][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
 out = {}

@@ -17,7 +17,7 @@ a = ap.parse_args()
 import mcbrat3d_amd as M  # noqa: E402
 from mcbrat3d_amd.integrator import new_RandomNumberSequence  # noqa: E402
 
-ap_opts = dict(o.split("=") for o in os.environ.get("PROF_OPTIONS", "").split() if "=" in o)  # e.g. PROF_OPTIONS="twoPhotons=1"
+ap_opts = dict(o.split("=") for o in os.environ.get("PROF_OPTIONS", "").split() if "=" in o)  # e.g. PROF_OPTIONS="jumpThreshold=16"
 lw = a.case == "lw"
 if a.case == "step":
     case, mu0, phi0, ppb, nb = cases.step_cloud(0.99), 1.0, 0.0, 100000, 100

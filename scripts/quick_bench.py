@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--bw", type=int, nargs="*", default=[-1], help="block walk (LDS-resident grids): -1 default, 0 off, 1 on")
     ap.add_argument("--n", type=int, default=128, help="landsat / radar: columns per side")
     ap.add_argument("--nz", type=int, default=64)
-    ap.add_argument("--opt", nargs="*", default=[], help="scheduling options by name, e.g. twoPhotons=0 pairThreshold=16,32 (comma: sweep)")
+    ap.add_argument("--opt", nargs="*", default=[], help="scheduling options by name, e.g. jumpThreshold=8,16 (comma: sweep)")
     ap.add_argument("--haze", type=float, default=100.0, help="case hazy: the Rayleigh component times this (optical depth 0.023 x haze)")
     a = ap.parse_args()
     import mcbrat3d_amd as M

@@ -92,6 +92,7 @@ step_profiles() {  # the measurement record of the shipped kernels: bench lines,
     rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_lw -- python3 $ROOT/bench.py --workload homogLW20x16 --steps 3 --warmup 1 --no-cpu-baseline > $P/stats_lw.log 2>&1 )
   bash scripts/pmc_profile.sh step r04/prof/pmc_step --thr 16 > $P/pmc_step.log 2>&1
   bash scripts/pmc_profile.sh landsat r04/prof/pmc_landsat --thr 20 > $P/pmc_landsat.log 2>&1
+  bash scripts/pmc_profile.sh lw r04/prof/pmc_lw > $P/pmc_lw.log 2>&1
   find $P -name "*kernel_stats.csv" | xargs -n1 head -3 | cut -c1-200
   echo profiles done
 }
@@ -124,19 +125,6 @@ print("LW value %.4g ms/step %.3f kernel_ms %.3f kernel %s bad %s" % (d["value"]
 PY
     echo "bench_lw wide=$wide rc=$rc out=$f.json"
   done
-}
-step_two() {  # two photons per lane on the 128x128x64 fields: off / on, thresholds of the exchange (development timing)
-  local log=$OUT/two_$(ts).log
-  { MCBRAT_DEBUG_TWO=1 timeout -k 10 240 python scripts/quick_bench.py --case landsat --ppb 1000000 --batches 100 --thr ${THR:-20} --reps 3 --counters --opt twoPhotons=0,1
-    timeout -k 10 400 python scripts/quick_bench.py --case landsat --ppb 1000000 --batches 100 --thr ${THR2:-16 24 32} --reps 2 --opt twoPhotons=1 pairThreshold=${PAIR:-8,16,32} swapThreshold=${SWAP:-16,32,65}
-    timeout -k 10 240 python scripts/quick_bench.py --case radar --ppb 1000000 --batches 100 --thr 24 --reps 2 --opt twoPhotons=0,1; } > $log 2>&1
-  grep "^opts\|lanes/phase\|two photons per lane" $log | cut -c1-400
-  echo "two log=$log"
-}
-step_pmc_two() {  # counters of the two-photons-per-lane experiment (128x128x64), beside the shipped kernel's
-  PROF_OPTIONS="twoPhotons=1" bash scripts/pmc_profile.sh landsat r04/pmc_landsat_two --thr 20 > $OUT/pmc_landsat_two.log 2>&1
-  PROF_OPTIONS="twoPhotons=0" bash scripts/pmc_profile.sh landsat r04/pmc_landsat_one --thr 20 > $OUT/pmc_landsat_one.log 2>&1
-  tail -3 $OUT/pmc_landsat_two.log | cut -c1-200
 }
 step_pmc_lw() {  # counters of config 4's kernel (one wavelength's launch), wide plan and without
   bash scripts/pmc_profile.sh lw r04/pmc_lw > $OUT/pmc_lw.log 2>&1

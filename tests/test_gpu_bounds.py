@@ -140,7 +140,6 @@ def test_wave_watchdog_of_the_face_by_face_kernel(M, monkeypatch):
         integ = M.new_Integrator(dom)
         integ.specifyParameters(minInverseTableSize=2001, useRayTracing=True, useRussianRoulette=False)
         integ.setTuning(eventThreshold=16, privateTallies=0, layerSkip=0, blockWalk=0)
-        integ.setOption(twoPhotons=0)
         photons = M.new_PhotonStream(0.5, 0.0, numberOfPhotons=10 ** 9)
         fates = integ.traceFates(dom, new_RandomNumberSequence(SEED), photons, n)
         bad, what = int(integ.counters()["badPhotons"]), integ.firstDrop()

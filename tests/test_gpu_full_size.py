@@ -103,16 +103,3 @@ def test_radar_like_full_grid_fates_and_batch_against_the_oracle(M):
     assert np.allclose(res["absorbedProfile"], prof, rtol=0.04, atol=3e-5 * np.max(prof) + 1e-9)
     integ.finalize()
 
-
-@pytest.mark.parametrize("make", ["landsat_like", "radar_like"])
-def test_two_photons_per_lane_are_bitwise_the_one_photon_kernel_at_full_size(M, make):
-    """trace_kernel<..., TWO> (two photons per lane in registers) only changes WHEN a lane works on
-    which photon: on the 128x128x64 fields the moment array of 2e7 photons is bit for bit that of the one-photon kernel,
-    whatever the thresholds of the exchange."""
-    dom = cases.product_domain(getattr(cases, make)())
-    calls = [(0, 10 ** 6, 20)]
-    one = _moments(M, dom, 0.5, 30.0, calls, tuning=dict(eventThreshold=20), options=dict(twoPhotons=0))
-    for opts in (dict(twoPhotons=1), dict(twoPhotons=1, pairThreshold=65, swapThreshold=65), dict(twoPhotons=1, pairThreshold=1, swapThreshold=1),
-                 dict(twoPhotons=1, pairThreshold=32, swapThreshold=8)):
-        two = _moments(M, dom, 0.5, 30.0, calls, tuning=dict(eventThreshold=20), options=opts)
-        assert np.array_equal(one, two), opts

@@ -22,7 +22,7 @@ def M():
 FUZZ = int(os.environ.get("MCBRAT_FLIGHT_FUZZ", "12"))  # seeds of the random differential test (raise it for a soak run)
 
 
-OPTIONS = ("twoPhotons", "pairThreshold", "swapThreshold")  # by name (mcbrat_set_option), the rest through setTuning
+OPTIONS = ("jumpThreshold", "crossThreshold")  # by name (mcbrat_set_option), the rest through setTuning
 
 
 def _run(M, case, mu0, phi0, rr, walk, tuning, n=12000):
@@ -53,23 +53,19 @@ def test_random_tunings_give_the_same_histories(M, seed):
     # privateTallies 4 / 5: the wide plan -- one workgroup of 1024 lanes per compute unit with the tallies in its LDS, the
     # optical grid beside them (4) or left in global memory (5: for the block walk, extinction per block in LDS) -- which
     # the library chooses by itself only for tally slabs too large to share a compute unit (config 4's 70 KB)
-    # two photons per lane (trace_kernel<..., TWO>: tallies in global memory, dense grid) against the one-photon kernel, with
-    # random thresholds of the exchange (65: never)
-    two = dict(twoPhotons=int(rng.integers(0, 2)), pairThreshold=int(rng.choice([1, 8, 16, 40, 65])), swapThreshold=int(rng.choice([1, 8, 24, 65])))
+    queues = dict(jumpThreshold=int(rng.choice([1, 8, 24])), crossThreshold=int(rng.choice([1, 8, 24])))  # (by name: mcbrat_set_option)
     layout = dict(privateTallies=int(rng.choice([0, 1, 4, 5])), brickLayout=int(rng.integers(0, 2)))
     if layout["privateTallies"] >= 4:
         layout.update(blockSize=0, brickLayout=0)
     for name, walk, base_tuning, tuning in (
-            ("face by face", dict(layerSkip=0, blockWalk=0), dict(eventThreshold=16, privateTallies=0, brickLayout=0, twoPhotons=0), {**sched, **layout, **two}),
-            ("layers + flight", dict(layerSkip=3, blockWalk=0, privateTallies=0, brickLayout=0), dict(eventThreshold=16, twoPhotons=0), {**sched, **two}),
-            ("layers + flight, two photons per lane", dict(layerSkip=3, blockWalk=0, privateTallies=0, brickLayout=0), dict(eventThreshold=16, twoPhotons=0),
-             {**{k: v for k, v in sched.items() if k != "blockSize"}, **two, "twoPhotons": 1}),
+            ("face by face", dict(layerSkip=0, blockWalk=0), dict(eventThreshold=16, privateTallies=0, brickLayout=0), {**sched, **layout}),
+            ("layers + flight", dict(layerSkip=3, blockWalk=0, privateTallies=0, brickLayout=0), dict(eventThreshold=16), {**sched, **queues}),
             # (layerSkip = 2: the layers without the clear-air flight, which the wide plan does not carry; privateTallies = 5:
             # with the grid in LDS too -- 4 -- the walk is the face-by-face one, the first row's)
             ("layers, wide plan", dict(layerSkip=2, blockWalk=0, brickLayout=0), dict(eventThreshold=16, privateTallies=0),
              {**{k: v for k, v in sched.items() if k != "blockSize"}, "privateTallies": 5}),
             ("block walk", dict(blockWalk=2), dict(eventThreshold=16),
-             {**{k: v for k, v in sched.items() if k != "blockSize"}, "privateTallies": int(rng.choice([1, 4, 5]))})):
+             {**{k: v for k, v in sched.items() if k != "blockSize"}, **queues, "privateTallies": int(rng.choice([1, 4, 5]))})):
         base = _run(M, case, mu0, phi0, rr, walk, base_tuning)
         got = _run(M, case, mu0, phi0, rr, walk, tuning)
         for f in base[0].dtype.names:
