@@ -181,7 +181,8 @@ def kernel_name(walk, thermal=False, lds_grid=None):
     if walk.get("blockWalk"):
         if walk.get("widePlan"):
             return "trace_block_kernel (mcbrat_blockwalk.hip: block walk, one workgroup of 1024 lanes per CU, tallies + tables%s in LDS%s)" % (
-                " + block numbers, optics in global memory" if walk.get("opticsInGlobalMemory") else " + grid", ", thermal source" if thermal else "")
+                " + block numbers, optics in global memory" if walk.get("opticsInGlobalMemory") else (" + block numbers and optics per block" if walk.get("opticsPerBlock") else " + grid"),
+                (", thermal source" + (" with the emission CDF's level and row sums in LDS" if walk.get("emissionCdfTopInLds") else "")) if thermal else "")
         return "trace_block_kernel (mcbrat_blockwalk.hip: block walk, grid + tallies + tables in LDS%s)" % (", thermal source" if thermal else "")
     return "trace_kernel (mcbrat_kernels.hip: %s%s%s)" % (
         "layer-skipping walk" if walk.get("layerSkip") else "face-by-face walk",

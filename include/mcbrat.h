@@ -212,7 +212,8 @@ int mcbrat_chain_after(mcbrat_ctx *ctx, mcbrat_ctx *previous);
  * (0 = memory bound), privateTallies (0 global atomics; 1 the library's plan: tallies private to a workgroup in LDS where the
  * slab fits beside a second workgroup, else the wide plan -- one workgroup of 1024 lanes per compute unit with up to its
  * whole 160 KB of LDS -- else global atomics; 2 private tallies without the optical grid in LDS; 3 as 1 without the wide plan;
- * 4 the wide plan even where the shared one would do; 5 as 4 with the per-cell optics left in global memory),
+ * 4 the wide plan even where the shared one would do; 5 as 4 with the per-cell optics left in global memory; 6 as 4 without
+ * the per-cell optics in LDS -- per block in LDS where every block is uniform in them, else as 5),
  * workgroup size (0 = automatic, 256, 512, 768; a fixed size rules the wide plan out), and how
  * many idle / surface lanes queue up before launches / surface reflections are served; brickLayout:
  * 0 dense optical grids, 1 4x4x4 bricks with unstored background bricks, 2 automatic (default). */
@@ -265,7 +266,8 @@ int mcbrat_set_walk_options(mcbrat_ctx *ctx, int32_t layerSkip, int32_t blockWal
  * flight's tables fit beside the rest), bit 3 the blockWalk option as set, bit 6 tallies private to a workgroup in LDS,
  * bit 4 the wide plan (a tally slab too large to share a compute unit's LDS: one workgroup of 1024 lanes per compute unit
  * owns up to its whole 160 KB), bit 5 the block walk with the per-cell optics left in global memory (extinction per block
- * in LDS).  Before grid and optics are loaded: the options. */
+ * in LDS), bit 7 the block walk with the optics per BLOCK in LDS (every block uniform in them), bit 8 the thermal source's level
+ * and row sums of the emission CDF staged in LDS.  Before grid and optics are loaded: the options. */
 int mcbrat_get_walk_mode(const mcbrat_ctx *ctx);
 
 /* The event threshold in use (after the first call of a domain: the one chosen by the trial launches). */

@@ -75,6 +75,9 @@ struct mcbrat_ctx {
   uint32_t *dBlockRec = nullptr;
   uint16_t *dBlockOf = nullptr;
   float *dBlockExt = nullptr;  // [nBlocks] extinction of each block
+  float *dBlockSsa = nullptr, *dBlockCum = nullptr;  // [nc][nBlocks] optics per block, where uniform (blockOpticsUniform)
+  uint16_t *dBlockPfi = nullptr;
+  bool blockOpticsUniform = false;
   int nBlocks = 0;
   int crossThreshold = 8;      // MCBRAT_CROSS_THRESHOLD
   int jumpThreshold = 8;       // MCBRAT_JUMP_THRESHOLD
@@ -411,13 +414,18 @@ int build_bricks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<f
 
 // Block walk (mcbrat_blockwalk.hip): the grid cut into axis-aligned blocks of cells that carry one extinction value
 // (mcbrat_block_decomposition, mcbrat_host.cpp), uploaded for the kernel.
-int build_blocks(mcbrat_ctx *c, const std::vector<float> &e) {
+int build_blocks(mcbrat_ctx *c, const std::vector<float> &e, const std::vector<float> &cu, const std::vector<float> &ssa,
+                 const std::vector<uint16_t> &pf, int nc) {
   const int nx = c->nx, ny = c->ny, nz = c->nz;
   const size_t nvox = (size_t)nx * ny * nz;
   c->nBlocks = 0;
   if (c->dBlockRec) { (void)hipFree(c->dBlockRec); c->dBlockRec = nullptr; }
   if (c->dBlockOf) { (void)hipFree(c->dBlockOf); c->dBlockOf = nullptr; }
   if (c->dBlockExt) { (void)hipFree(c->dBlockExt); c->dBlockExt = nullptr; }
+  if (c->dBlockSsa) { (void)hipFree(c->dBlockSsa); c->dBlockSsa = nullptr; }
+  if (c->dBlockCum) { (void)hipFree(c->dBlockCum); c->dBlockCum = nullptr; }
+  if (c->dBlockPfi) { (void)hipFree(c->dBlockPfi); c->dBlockPfi = nullptr; }
+  c->blockOpticsUniform = false;
   // only grids that can live in LDS are walked this way (plan_launch decides); bounds are packed in 16 bits
   if (nvox > 65536 || nx > 65535 || ny > 65535 || nz > 65535) return 0;
   std::vector<uint16_t> of(nvox);
@@ -428,6 +436,26 @@ int build_blocks(mcbrat_ctx *c, const std::vector<float> &e) {
   for (size_t v = 0; v < nvox; ++v) blockExt[of[v]] = e[v];  // (one value per block by construction)
   if (upload(c, &c->dBlockRec, rec.data(), (size_t)4 * nb) || upload(c, &c->dBlockOf, of.data(), of.size()) ||
       upload(c, &c->dBlockExt, blockExt.data(), blockExt.size())) return 1;
+  // Blocks are cut by extinction; where every block is uniform in the other optics too (a homogeneous medium, slabs: the
+  // broadband and I3RC test domains) a collision needs no per-cell record at all -- optics per block, in LDS
+  std::vector<float> bSsa((size_t)nc * nb), bCum((size_t)nc * nb);
+  std::vector<uint16_t> bPfi((size_t)nc * nb);
+  std::vector<char> seen((size_t)nb, 0);
+  bool uniform = true;
+  for (size_t v = 0; v < nvox && uniform; ++v) {
+    const size_t b = of[v];
+    for (int k = 0; k < nc && uniform; ++k) {
+      const size_t i = (size_t)k * nvox + v, j = (size_t)k * nb + b;
+      if (!seen[b]) { bSsa[j] = ssa[i]; bCum[j] = cu[i]; bPfi[j] = pf[i]; }
+      else uniform = std::memcmp(&bSsa[j], &ssa[i], 4) == 0 && std::memcmp(&bCum[j], &cu[i], 4) == 0 && bPfi[j] == pf[i];
+    }
+    seen[b] = 1;
+  }
+  if (uniform) {
+    if (upload(c, &c->dBlockSsa, bSsa.data(), bSsa.size()) || upload(c, &c->dBlockCum, bCum.data(), bCum.size()) ||
+        upload(c, &c->dBlockPfi, bPfi.data(), bPfi.size())) return 1;
+    c->blockOpticsUniform = true;
+  }
   c->nBlocks = nb;
   return 0;
 }
@@ -473,6 +501,10 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
     for (int i = 0; i <= c->nx && u; ++i) u = std::fabs((c->xe[i] - p.x0) * p.invCellX - i) <= 1e-6;
     for (int i = 0; i <= c->ny && u; ++i) u = std::fabs((c->ye[i] - p.y0) * p.invCellY - i) <= 1e-6;
     p.xyNearUniform = u ? 1 : 0;
+    bool uz = true;
+    const double invCellZ = (double)c->nz / (p.zMax - p.z0);
+    for (int i = 0; i <= c->nz && uz; ++i) uz = std::fabs((c->ze[i] - p.z0) * invCellZ - i) <= 1e-6;
+    p.zNearUniform = uz ? 1 : 0;
   }
   p.edges = c->dEdges;
   if (use_bricks(c)) {
@@ -503,6 +535,7 @@ void fill_params(mcbrat_ctx *c, DevParams &p) {
   p.useHybrid = c->useHybrid; p.numOrdersOrig = c->numOrdersOrig; p.useRRIntensity = c->useRRIntensity; p.zetaMin = c->zetaMin;
   p.limitContrib = c->limitContrib; p.maxContrib = c->maxContrib;
   p.nBlocks = c->nBlocks; p.blockRec = reinterpret_cast<const uint4 *>(c->dBlockRec); p.blockOf = c->dBlockOf; p.blockExt = c->dBlockExt;
+  p.blockSsa = c->dBlockSsa; p.blockCum = c->dBlockCum; p.blockPfi = c->dBlockPfi;
   p.crossThreshold = std::max(1, std::min(64, c->crossThreshold));
   p.jumpThreshold = std::max(1, std::min(64, c->jumpThreshold));
   p.bad = c->dBad;
@@ -549,7 +582,9 @@ struct LaunchPlan {
   // (16 waves, 4 per SIMD) with up to the whole LDS, tallies in LDS as for the small domains instead of one memory-side
   // atomic per deposit (config 4 waited 57 % of its wave time behind them).  Flux runs only.
   bool wide;
-  bool blockLite;  // wide plan, block walk, per-cell optics in global memory (trace_block_kernel<..., OPT_LDS = false>)
+  bool blockLite;  // wide plan, block walk without the per-cell optics in LDS (trace_block_kernel<..., OPT = 1 or 2>)
+  int optics;      // block walk: where a collision finds its cell's optics: 0 per cell in LDS, 1 per cell in global memory, 2 per block in LDS
+  bool cdfTop;     // block walk, thermal source: level and row sums of the emission CDF staged in LDS
   int block;
   size_t lds;
 };
@@ -562,7 +597,7 @@ bool blocks_worth_it(const mcbrat_ctx *c) {
 
 LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
   LaunchPlan L;
-  L.wide = false; L.blockLite = false;
+  L.wide = false; L.blockLite = false; L.optics = 0; L.cdfTop = false;
   const size_t edges = sizeof(double) * (size_t)(c->nx + c->ny + c->nz + 3);
   const size_t tbl = sizeof(float) * (size_t)c->tblTotalFloats;
   const size_t slab = sizeof(long long) * slabStride + 16;
@@ -589,17 +624,22 @@ LaunchPlan plan_launch(const mcbrat_ctx *c, size_t slabStride) {
     L.block = 1024;
     // block walk with the per-cell optics left in global memory: what a medium made of blocks whose grid does not fit still gets
     if (!L.gridLds && blocks_worth_it(c) && c->gridLdsMode != 0) {
-      const BlockLds B = block_lds_layout(c->nx, c->ny, c->nz, c->nc, slabStride, c->nBlocks, (size_t)c->tblTotalFloats, false);
-      const BlockLds B0 = block_lds_layout(c->nx, c->ny, c->nz, c->nc, slabStride, c->nBlocks, 0, false);
-      if (B.total <= cuLds) { L.blockLite = true; L.tblLds = true; }
-      else if (B0.total <= cuLds) { L.blockLite = true; L.tblLds = false; }
+      const int opt = (c->blockOpticsUniform && c->gridLdsMode != 2) ? 2 : 1;  // (gridLdsMode 2: per-cell optics in global memory asked for, tests)
+      const BlockLds B = block_lds_layout(c->nx, c->ny, c->nz, c->nc, slabStride, c->nBlocks, (size_t)c->tblTotalFloats, opt);
+      const BlockLds B0 = block_lds_layout(c->nx, c->ny, c->nz, c->nc, slabStride, c->nBlocks, 0, opt);
+      if (B.total <= cuLds) { L.blockLite = true; L.tblLds = true; L.optics = opt; }
+      else if (B0.total <= cuLds) { L.blockLite = true; L.tblLds = false; L.optics = opt; }
     }
+    if (blocks_worth_it(c) && (L.gridLds || L.blockLite) && c->srcKind != 0)  // the emission CDF's level and row sums beside them, where they fit
+      L.cdfTop = block_lds_layout(c->nx, c->ny, c->nz, c->nc, slabStride, c->nBlocks, L.tblLds ? (size_t)c->tblTotalFloats : 0, L.optics, true).total <= cuLds;
     return L;
   }
   const size_t flyLds = per_layer_lds(c->nz, c->flyNbx * c->flyNby) - bg;
   L.fly = flight_wanted(c) && !L.gridLds && !L.brick && c->nDir == 0 && L.lds + flyLds <= kLdsBudget;
   if (L.fly) L.lds += flyLds;
   L.block = c->blockSize > 0 ? c->blockSize : (L.gridLds ? 768 : ((L.tblLds || L.priv) && L.lds > 16 * 1024 ? 512 : 256));
+  if (blocks_worth_it(c) && L.priv && L.gridLds && c->srcKind != 0)
+    L.cdfTop = block_lds_layout(c->nx, c->ny, c->nz, c->nc, slabStride, c->nBlocks, L.tblLds ? (size_t)c->tblTotalFloats : 0, 0, true).total <= kLdsBudget;
   return L;
 }
 
@@ -722,7 +762,7 @@ bool block_walk_applies(const mcbrat_ctx *c, const LaunchPlan &L) {
   return blocks_worth_it(c) && ((L.priv && L.gridLds) || L.blockLite);
 }
 
-template <int BLOCK, bool TBL, bool DBG, bool EMIT, int SIMPLE, bool OPT = true>
+template <int BLOCK, bool TBL, bool DBG, bool EMIT, int SIMPLE, int OPT = 0>
 int launch_block_s(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   auto kernel = trace_block_kernel<BLOCK, TBL, DBG, EMIT, SIMPLE, OPT>;
   if (lds + 512 > c->ldsPerCU) return fail(c, "computeRadiativeTransfer: the block-walk tables do not fit the LDS of a compute unit.");
@@ -744,28 +784,39 @@ int launch_block_s(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   return 0;
 }
 
-template <int BLOCK, bool TBL, bool DBG, bool EMIT, bool OPT = true>
+template <int BLOCK, bool TBL, bool DBG, bool EMIT, int OPT = 0>
 int launch_block_e(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   // equally spaced axes, one component, no surface description: the instantiation with those decided at compile time
   const bool simple = c->xyRegular && c->zRegular && c->nc == 1 && c->surfNumX == 0;
-  if constexpr (OPT && BLOCK != 1024) {
+  if constexpr (OPT == 0 && BLOCK != 1024) {
     if (simple && c->ny == 1 && !DBG) return launch_block_s<BLOCK, TBL, DBG, EMIT, 2, OPT>(c, p, lds, nBatches);  // an x-z problem
+  }
+  if constexpr (!DBG && (BLOCK == 1024 || BLOCK == 768)) {
+    // no axis equally spaced by the reference's single-precision test, every axis equally spaced to 1e-6 of a cell (0.1 km cells):
+    // the same cells as the general instantiation finds, with nothing left to decide at run time (SIMPLE = 3)
+    if (!c->xyRegular && !c->zRegular && p.xyNearUniform && p.zNearUniform && c->nc == 1 && c->surfNumX == 0 && !getenv("MCBRAT_NO_SIMPLE3"))
+      return launch_block_s<BLOCK, TBL, DBG, EMIT, 3, OPT>(c, p, lds, nBatches);
   }
   return simple ? launch_block_s<BLOCK, TBL, DBG, EMIT, 1, OPT>(c, p, lds, nBatches) : launch_block_s<BLOCK, TBL, DBG, EMIT, 0, OPT>(c, p, lds, nBatches);
 }
 
-template <int BLOCK, bool TBL, bool DBG, bool OPT = true>
+template <int BLOCK, bool TBL, bool DBG, int OPT = 0>
 int launch_block_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   return c->srcKind == 0 ? launch_block_e<BLOCK, TBL, DBG, false, OPT>(c, p, lds, nBatches) : launch_block_e<BLOCK, TBL, DBG, true, OPT>(c, p, lds, nBatches);
 }
 
 int launch_block(mcbrat_ctx *c, DevParams &p, const LaunchPlan &L, bool debug, int nBatches) {
+  p.cdfTopLds = L.cdfTop ? 1 : 0;
   const size_t lds = block_lds_layout(c->nx, c->ny, c->nz, c->nc, (size_t)p.slabStride, c->nBlocks,
-                                      L.tblLds ? (size_t)c->tblTotalFloats : 0, !L.blockLite).total;
+                                      L.tblLds ? (size_t)c->tblTotalFloats : 0, L.blockLite ? L.optics : 0, L.cdfTop).total;
   if (L.wide) {  // one workgroup per compute unit: 1024 lanes (the instrumented instantiation: 512)
+    if (L.blockLite && L.optics == 2) {
+      if (debug) return L.tblLds ? launch_block_t<512, true, true, 2>(c, p, lds, nBatches) : launch_block_t<512, false, true, 2>(c, p, lds, nBatches);
+      return L.tblLds ? launch_block_t<1024, true, false, 2>(c, p, lds, nBatches) : launch_block_t<1024, false, false, 2>(c, p, lds, nBatches);
+    }
     if (L.blockLite) {
-      if (debug) return L.tblLds ? launch_block_t<512, true, true, false>(c, p, lds, nBatches) : launch_block_t<512, false, true, false>(c, p, lds, nBatches);
-      return L.tblLds ? launch_block_t<1024, true, false, false>(c, p, lds, nBatches) : launch_block_t<1024, false, false, false>(c, p, lds, nBatches);
+      if (debug) return L.tblLds ? launch_block_t<512, true, true, 1>(c, p, lds, nBatches) : launch_block_t<512, false, true, 1>(c, p, lds, nBatches);
+      return L.tblLds ? launch_block_t<1024, true, false, 1>(c, p, lds, nBatches) : launch_block_t<1024, false, false, 1>(c, p, lds, nBatches);
     }
     if (debug) return L.tblLds ? launch_block_t<512, true, true>(c, p, lds, nBatches) : launch_block_t<512, false, true>(c, p, lds, nBatches);
     return L.tblLds ? launch_block_t<1024, true, false>(c, p, lds, nBatches) : launch_block_t<1024, false, false>(c, p, lds, nBatches);
@@ -837,7 +888,10 @@ int autotune(mcbrat_ctx *c, DevParams p, unsigned long long ppb, int nBatches) {
     // large ones), and the trial is left for a later, larger call
     // (the thermal source: photons start inside the medium and most end at their first roulette -- few lanes are ever on a
     // long walk, and waiting for 24 of them starves the event phase: 4-8 measured best on config 4, 24 costs 8 %)
-    c->eventThreshold = c->srcKind != 0 ? 8 : (plan_launch(c, (size_t)p.slabStride).gridLds ? 16 : 24);
+    // (the block walk has no walk loop: its threshold only says when a wave has little else to do than its queued work --
+    // 16-32 measured best on config 4's wide kernel too, 8 costs it 2.5 %)
+    const LaunchPlan L0 = plan_launch(c, (size_t)p.slabStride);
+    c->eventThreshold = block_walk_applies(c, L0) ? 16 : (c->srcKind != 0 ? 8 : (L0.gridLds ? 16 : 24));
     return 0;
   }
   const int nb = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)nBatches, want / std::max<unsigned long long>(1, ppb)));
@@ -919,7 +973,7 @@ void mcbrat_destroy(mcbrat_ctx *c) {
   (void)sync_all(c);
   void *bufs[] = {c->dEdges, c->dExt, c->dCum, c->dSsa, c->dRelArea, c->dPfi, c->dTables, c->dVoxelCDF,
                   c->dEventCounters, c->dLast, c->dMomentsOwned, c->dBrickTable, c->dExtB,
-                  c->dBlockRec, c->dBlockOf, c->dBlockExt, c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dExtWalk, c->dBgVal, c->dFlyRange, c->dSurfX, c->dSurfY, c->dSurfRefl,
+                  c->dBlockRec, c->dBlockOf, c->dBlockExt, c->dBlockSsa, c->dBlockCum, c->dBlockPfi, c->dCumB, c->dSsaB, c->dPfiB, c->dBgExt, c->dBgCum, c->dBgSsa, c->dBgPfi, c->dLayerExt, c->dRec, c->dLayerRun, c->dLayerRunT, c->dExtWalk, c->dBgVal, c->dFlyRange, c->dSurfX, c->dSurfY, c->dSurfRefl,
                   c->dBad, c->dFreqCdf, c->dFreqCounts, c->dDirData, c->dFwd, c->dFwdOrig};
   if (c->hBad) (void)hipHostFree(c->hBad);
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -1027,7 +1081,7 @@ int mcbrat_set_optics(mcbrat_ctx *c, int32_t nc, const double *totalExt, const d
   }
   c->bricksBuilt = false;
   if (build_bricks(c, e, cu, s, pf, nc)) return 1;
-  if (build_blocks(c, e)) return 1;
+  if (build_blocks(c, e, cu, s, pf, nc)) return 1;
   c->nc = nc;
   c->albedo = (float)albedo;
   c->maxPfi = maxPfi;
@@ -1309,11 +1363,12 @@ int mcbrat_set_tuning(mcbrat_ctx *c, int32_t blocksPerCU, int32_t eventThreshold
   if (maxBatchesInFlight >= 0) c->maxBatchesInFlight = maxBatchesInFlight;
   // privateTallies: 0 global atomics; 1 the library's plan; 2 private tallies without the optical grid in LDS; 3 as 1 without the
   // wide plan (a slab too large for a shared compute unit then tallies with global atomics); 4 the wide plan (one workgroup
-  // of 1024 lanes per compute unit) even where the shared plan would do; 5 as 4 with the per-cell optics left in global memory
+  // of 1024 lanes per compute unit) even where the shared plan would do; 5 as 4 with the per-cell optics left in global memory;
+  // 6 as 4 without the per-cell optics in LDS: per block in LDS where every block is uniform in them, else as 5
   if (privateTallies >= 0) {
-    if (privateTallies > 5) return fail(c, "set_tuning: privateTallies must be 0 ... 5");
+    if (privateTallies > 6) return fail(c, "set_tuning: privateTallies must be 0 ... 6");
     c->privMode = privateTallies ? 1 : 0;
-    c->gridLdsMode = privateTallies == 2 ? 0 : (privateTallies == 5 ? 2 : 1);
+    c->gridLdsMode = privateTallies == 2 ? 0 : (privateTallies == 5 ? 2 : (privateTallies == 6 ? 3 : 1));
     c->wideMode = privateTallies == 3 ? 0 : (privateTallies >= 4 ? 2 : c->wideDefault);
     c->tuned = false;
   }
@@ -1438,7 +1493,8 @@ int mcbrat_get_walk_mode(const mcbrat_ctx *c) {
     LaunchPlan L = plan_launch(c, 2 * ncol + ncol * c->nz);
     if (L.priv && L.brick) { L.priv = false; L.gridLds = false; }
     m = (c->layerSkip ? 1 : 0) | (block_walk_applies(c, L) ? 2 : 0) | (L.fly ? 4 : 0) | (c->blockWalk ? 8 : 0) |
-        (L.wide ? 16 : 0) | (L.blockLite ? 32 : 0) | (L.priv ? 64 : 0);
+        (L.wide ? 16 : 0) | ((L.blockLite && L.optics == 1) ? 32 : 0) | (L.priv ? 64 : 0) | ((L.blockLite && L.optics == 2) ? 128 : 0) |
+        (L.cdfTop ? 256 : 0);
   }
   return m;
 }

@@ -34,6 +34,15 @@ __device__ __forceinline__ int locate_z(const double *ze, int nz, bool regular, 
   if (!regular) return find_cell(ze, nz, z);
   return min(max((int)((z - z0) * invDz), 0), nz - 1);  // the reference's own map on a regular axis (findZIndex :1580-1592)
 }
+// find_cell's answer -- the largest i with e[i] <= v, clamped to [0, n-1] -- on an axis whose edges are equally spaced to 1e-6 of
+// a cell: the division is right to within one cell, the edge table decides (no bisection)
+__device__ __forceinline__ int locate_near_uniform(const double *e, int n, double x0, double invCell, double v) {
+  int i = min(max((int)((v - x0) * invCell), 0), n - 1);
+  const double lo = e[i], hi = e[i + 1];
+  i += (v >= hi && i < n - 1) ? 1 : 0;
+  i -= (v < lo && i > 0) ? 1 : 0;
+  return i;
+}
 
 // DEBUG: cell index along a periodic axis counted through the periodic images (faces crossed = |difference|)
 __device__ __forceinline__ long long unwrapped_index(const double *e, int n, double x0, double L, double invL, double x) {
@@ -43,24 +52,31 @@ __device__ __forceinline__ long long unwrapped_index(const double *e, int n, dou
 
 // LDS layout of trace_block_kernel (byte offsets), computed the same way by the host (plan_launch) and the kernel
 struct BlockLds {
-  size_t slab, cursor, rec, ext, ssa, cum, pfi, blockOf, tbl, total;
+  size_t slab, cursor, rec, cdf, ext, ssa, cum, pfi, blockOf, tbl, total;
 };
-// opticsLds = false (OPT_LDS = false below): the per-cell optics stay in global memory and LDS holds the extinction per
-// BLOCK instead of per cell -- 2 bytes per cell (its block) instead of 12, for domains whose tally slab takes most of a
-// compute unit's 160 KB (broadband 20 x 20 x 20: 70 KB of tallies + 36 KB of table + 16 KB of block numbers).
+// optics: where a collision finds single-scattering albedo, cumulative fractions and phase-function index of its cell (OPT below)
+//   0  per cell in LDS, beside the extinction per cell (the small domains: step cloud, plane parallel);
+//   1  per cell in global memory (L2: a few tens of KB), LDS holds the extinction per BLOCK -- 2 bytes per cell (its block)
+//      instead of 12, for domains whose tally slab takes most of a compute unit's 160 KB (broadband 20 x 20 x 20: 70 KB of
+//      tallies + 36 KB of table + 16 KB of block numbers);
+//   2  per BLOCK in LDS, where every block is uniform in them too (a homogeneous medium, slabs): no gather at a collision.
+// cdfTop: the thermal source's level and row sums of the emission CDF (nz + ny * nz doubles) staged in LDS: ten of the fifteen
+// dependent reads of a launch's three bisections stay on chip.
 __host__ __device__ inline BlockLds block_lds_layout(int nx, int ny, int nz, int nc, size_t slabLen, int nBlocks, size_t tblFloats,
-                                                      bool opticsLds = true) {
+                                                      int optics = 0, bool cdfTop = false) {
   BlockLds L;
   const size_t nvox = (size_t)nx * ny * nz;
+  const size_t nB4 = ((size_t)nBlocks + 3) & ~(size_t)3;
   size_t o = sizeof(double) * (size_t)(nx + ny + nz + 3);
   L.slab = o; o += sizeof(long long) * slabLen;
   L.cursor = o; o += 16;
   o = (o + 15) & ~(size_t)15;
   L.rec = o; o += 16 * (size_t)nBlocks;
-  L.ext = o; o += opticsLds ? 4 * nvox : 4 * (((size_t)nBlocks + 3) & ~(size_t)3);
-  L.ssa = o; o += opticsLds ? 4 * nvox * nc : 0;
-  L.cum = o; o += (opticsLds && nc > 1) ? 4 * nvox * nc : 0;  // (read only when there is more than one component)
-  L.pfi = o; o += opticsLds ? 2 * ((nvox * nc + 1) & ~(size_t)1) : 0;
+  L.cdf = o; o += cdfTop ? sizeof(double) * ((size_t)nz + (size_t)ny * nz) : 0;
+  L.ext = o; o += optics == 0 ? 4 * nvox : 4 * nB4;
+  L.ssa = o; o += optics == 0 ? 4 * nvox * nc : (optics == 2 ? 4 * nB4 * nc : 0);
+  L.cum = o; o += nc > 1 ? (optics == 0 ? 4 * nvox * nc : (optics == 2 ? 4 * nB4 * nc : 0)) : 0;  // (read only when there is more than one component)
+  L.pfi = o; o += optics == 0 ? 2 * ((nvox * nc + 1) & ~(size_t)1) : (optics == 2 ? 2 * nB4 * nc : 0);
   L.blockOf = o; o += 2 * ((nvox + 1) & ~(size_t)1);
   o = (o + 3) & ~(size_t)3;
   L.tbl = o; o += 4 * tblFloats;
@@ -74,19 +90,24 @@ __host__ __device__ inline BlockLds block_lds_layout(int nx, int ny, int nz, int
 // Lambertian albedo -- the I3RC step cloud, plane-parallel and homogeneous domains.  What the general kernel decides
 // at run time from wave-uniform parameters (bisection or division, how many components, surface description or albedo)
 // is decided at compile time here: the branches and the scalar registers they keep alive leave the loop.
+// SIMPLE = 3 (round 4): one component and the domain's albedo as 1, on axes that the reference's test calls NOT equally spaced but
+// that are equally spaced to 1e-6 of a cell -- its test compares with a spacing held in single precision (new_Integrator :140,
+// :163-181), so a grid of 0.1 km cells, config 4's, fails it.  Cells are then what the edge table says (find_cell's answer, bit for
+// bit the general instantiation's), found by division + table check instead of bisection, with nothing left to decide at run
+// time: the general instantiation spills 116 scalar registers into vector lanes on that domain.
 // SIMPLE = 2: as 1, and the domain is one cell wide in y (the I3RC step cloud and the plane-parallel cases are x-z
 // problems): with a uniform surface nothing depends on the y position, so the y part of the leg origin, of the face
 // distances and of the cell look-ups is compiled out (the direction keeps its y component; the instrumented
 // instantiation keeps y, it counts the periodic y faces a leg crosses as the reference does).
-// OPT_LDS = false: single-scattering albedo, cumulative fractions and phase-function index of a cell are read from global
-// memory at a collision (they sit in L2: a few tens of KB), the extinction comes from the cell's block; see block_lds_layout.
-// Workgroups of 1024 lanes are ONE per compute unit (they own most of its 160 KB of LDS): 4 waves per SIMD, 128 registers.
-template <int BLOCK, bool TBL_LDS, bool DEBUG, bool EMIT, int SIMPLE, bool OPT_LDS = true>
+// OPT: where a collision finds the optics of its cell (0 per cell in LDS, 1 per cell in global memory, 2 per block in LDS), see
+// block_lds_layout.  Workgroups of 1024 lanes are ONE per compute unit (they own most of its 160 KB of LDS): 4 waves per SIMD.
+template <int BLOCK, bool TBL_LDS, bool DEBUG, bool EMIT, int SIMPLE, int OPT = 0>
 __global__ void __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK > 512 ? BLOCK / 128 : MCBRAT_MIN_WAVES_PER_SIMD))
 trace_block_kernel(const DevParams p) {
   constexpr bool NOY = SIMPLE == 2 && !DEBUG;
-  const bool xyRegular = SIMPLE != 0 ? true : p.xyRegular != 0;
-  const bool zRegular = SIMPLE != 0 ? true : p.zRegular != 0;
+  constexpr bool NEAR = SIMPLE == 3;  // every axis: not regular by the reference's test, equally spaced to 1e-6 of a cell
+  const bool xyRegular = NEAR ? false : (SIMPLE != 0 ? true : p.xyRegular != 0);
+  const bool zRegular = NEAR ? false : (SIMPLE != 0 ? true : p.zRegular != 0);
   const int nc = SIMPLE != 0 ? 1 : p.nc;
   extern __shared__ __align__(16) unsigned char smem_raw[];
 #ifdef MCBRAT_POISON  // audit build: whatever the kernel reads from LDS before it wrote it reads 0xff..
@@ -100,11 +121,15 @@ trace_block_kernel(const DevParams p) {
   const int ncol = p.nx * p.ny;
   const int nvox = ncol * p.nz;
   const int slabLen = (int)p.slabStride;
-  const BlockLds lay = block_lds_layout(p.nx, p.ny, p.nz, nc, (size_t)slabLen, p.nBlocks, TBL_LDS ? (size_t)p.tblTotalFloats : 0, OPT_LDS);
+  const bool cdfTop = EMIT && p.cdfTopLds != 0;  // (wave-uniform)
+  const BlockLds lay = block_lds_layout(p.nx, p.ny, p.nz, nc, (size_t)slabLen, p.nBlocks, TBL_LDS ? (size_t)p.tblTotalFloats : 0, OPT, cdfTop);
+  const int nB4 = (p.nBlocks + 3) & ~3;
   long long *s_slab = reinterpret_cast<long long *>(smem_raw + lay.slab);
   unsigned *s_cursor = reinterpret_cast<unsigned *>(smem_raw + lay.cursor);
   uint4 *s_blockRec = reinterpret_cast<uint4 *>(smem_raw + lay.rec);
-  float *s_ext = reinterpret_cast<float *>(smem_raw + lay.ext);         // [nvox]; OPT_LDS = false: [nBlocks], the blocks' extinction
+  float *s_ext = reinterpret_cast<float *>(smem_raw + lay.ext);         // [nvox]; OPT != 0: [nBlocks], the blocks' extinction
+  double *s_cdfLevel = reinterpret_cast<double *>(smem_raw + lay.cdf);  // [nz] level sums of the emission CDF, then [nz][ny] row sums (cdfTop)
+  double *s_cdfRow = s_cdfLevel + p.nz;
   float *s_ssa = reinterpret_cast<float *>(smem_raw + lay.ssa);         // [nc][nvox]
   float *s_cum = reinterpret_cast<float *>(smem_raw + lay.cum);         // [nc][nvox]
   uint16_t *s_pfi = reinterpret_cast<uint16_t *>(smem_raw + lay.pfi);   // [nc][nvox]
@@ -124,20 +149,31 @@ trace_block_kernel(const DevParams p) {
   if (threadIdx.x == 0) s_cursor[0] = 0;
   for (int i = threadIdx.x; i < p.nBlocks; i += BLOCK) s_blockRec[i] = p.blockRec[i];
   for (int i = threadIdx.x; i < nvox; i += BLOCK) s_blockOf[i] = p.blockOf[i];
-  if (OPT_LDS) {
+  if (OPT == 0) {
     for (int i = threadIdx.x; i < nvox; i += BLOCK) s_ext[i] = p.ext[i];
     for (int i = threadIdx.x; i < nc * nvox; i += BLOCK) { s_ssa[i] = p.ssa[i]; s_pfi[i] = p.pfi[i]; }
     if (nc > 1)
       for (int i = threadIdx.x; i < nc * nvox; i += BLOCK) s_cum[i] = p.cum[i];
   } else {
     for (int i = threadIdx.x; i < p.nBlocks; i += BLOCK) s_ext[i] = p.blockExt[i];
+    if (OPT == 2) {  // per-block optics, [component][nB4]
+      for (int i = threadIdx.x; i < nc * nB4; i += BLOCK) {
+        const int k = i / nB4, b = i - k * nB4;
+        if (b < p.nBlocks) { s_ssa[i] = p.blockSsa[k * p.nBlocks + b]; s_pfi[i] = p.blockPfi[k * p.nBlocks + b]; if (nc > 1) s_cum[i] = p.blockCum[k * p.nBlocks + b]; }
+      }
+    }
+  }
+  if (cdfTop) {  // newPhotonStream_BBEmission's levelWeights(k) = voxelWeights(nx, ny, k) and colWeights(j, k) = voxelWeights(nx, j, k) (monteCarloIllumination.f95:56-57)
+    const long long nxy = (long long)p.nx * p.ny;
+    for (int i = threadIdx.x; i < p.nz; i += BLOCK) s_cdfLevel[i] = p.voxelCDF[((long long)p.nx - 1) + (long long)p.nx * (p.ny - 1) + nxy * i];
+    for (int i = threadIdx.x; i < p.ny * p.nz; i += BLOCK) { const int k = i / p.ny, j = i - k * p.ny; s_cdfRow[i] = p.voxelCDF[((long long)p.nx - 1) + (long long)p.nx * j + nxy * k]; }
   }
   __syncthreads();
-  // optics of a cell (collisions) / extinction of a cell's block: LDS, or global memory and the block's value (OPT_LDS = false)
-  auto cumAt = [&](int i) -> float { if constexpr (OPT_LDS) return s_cum[i]; else return p.cum[i]; };
-  auto ssaAt = [&](int i) -> float { if constexpr (OPT_LDS) return s_ssa[i]; else return p.ssa[i]; };
-  auto pfiAt = [&](int i) -> int { if constexpr (OPT_LDS) return (int)s_pfi[i]; else return (int)p.pfi[i]; };
-  auto extOfCell = [&](int cell) -> float { if constexpr (OPT_LDS) return s_ext[cell]; else return s_ext[s_blockOf[cell]]; };
+  // optics of a cell (collisions): component k of cell `cell`
+  auto cumAt = [&](int k, int cell) -> float { if constexpr (OPT == 0) return s_cum[k * nvox + cell]; else if constexpr (OPT == 1) return p.cum[k * nvox + cell]; else return s_cum[k * nB4 + s_blockOf[cell]]; };
+  auto ssaAt = [&](int k, int cell) -> float { if constexpr (OPT == 0) return s_ssa[k * nvox + cell]; else if constexpr (OPT == 1) return p.ssa[k * nvox + cell]; else return s_ssa[k * nB4 + s_blockOf[cell]]; };
+  auto pfiAt = [&](int k, int cell) -> int { if constexpr (OPT == 0) return (int)s_pfi[k * nvox + cell]; else if constexpr (OPT == 1) return (int)p.pfi[k * nvox + cell]; else return (int)s_pfi[k * nB4 + s_blockOf[cell]]; };
+  auto extOfCell = [&](int cell) -> float { if constexpr (OPT == 0) return s_ext[cell]; else return s_ext[s_blockOf[cell]]; };
   const float *__restrict__ tbl = TBL_LDS ? s_tbl : p.tables;
   const int offY = p.nx + 1, offZ = p.nx + p.ny + 2;  // edge table offsets
   const double invDz = (double)p.nz / (p.zMax - p.z0);
@@ -195,7 +231,7 @@ trace_block_kernel(const DevParams p) {
     }
     if (xyRegular) return min(max((int)((xw - p.x0) * p.invDX), 0), p.nx - 1);
     double o = 0.0;
-    return locate_periodic(s_edge, p.nx, p.x0, p.Lx, p.invLx, p.invCellX, p.xyNearUniform != 0, o, xw);
+    return locate_periodic(s_edge, p.nx, p.x0, p.Lx, p.invLx, p.invCellX, NEAR || p.xyNearUniform != 0, o, xw);
   };
   auto locY = [&](double yw, bool canLeave, bool force = false) {
     if (NOY) return 0;
@@ -207,7 +243,7 @@ trace_block_kernel(const DevParams p) {
     }
     if (xyRegular) return min(max((int)((yw - p.y0) * p.invDY), 0), p.ny - 1);
     double o = 0.0;
-    return locate_periodic(s_edge + offY, p.ny, p.y0, p.Ly, p.invLy, p.invCellY, p.xyNearUniform != 0, o, yw);
+    return locate_periodic(s_edge + offY, p.ny, p.y0, p.Ly, p.invLy, p.invCellY, NEAR || p.xyNearUniform != 0, o, yw);
   };
   auto inRange = [](int j, unsigned r) { return min(max(j, (int)(r & 0xffffu)), (int)(r >> 16) - 1); };
   // TEST ONLY (DevParams::legacyTies): the tie handling from before the three fixes the soak runs led to, to show that the
@@ -221,7 +257,7 @@ trace_block_kernel(const DevParams p) {
     const int cell = ix + p.nx * (iy + p.ny * iz);
     const unsigned blk = s_blockOf[cell];
     const uint4 rec = s_blockRec[blk];
-    if constexpr (OPT_LDS) extCur = s_ext[cell]; else extCur = s_ext[blk];
+    if constexpr (OPT == 0) extCur = s_ext[cell]; else extCur = s_ext[blk];
     rx = rec.x; rz = rec.z;
     if (!NOY) ry = rec.y;
     const int fx = dx >= 0.0f ? (int)(rx >> 16) : (int)(rx & 0xffffu);
@@ -399,8 +435,9 @@ trace_block_kernel(const DevParams p) {
               } else {  // atmosphere :495-510
                 const float rn = u01(r[1]);
                 const long long nxy = (long long)p.nx * p.ny;
-                const int ik = find_cdf(p.voxelCDF + ((long long)p.nx - 1) + (long long)p.nx * (p.ny - 1), p.nz, nxy, rn);
-                const int ij = find_cdf(p.voxelCDF + ((long long)p.nx - 1) + nxy * (ik - 1), p.ny, p.nx, rn);
+                // (level and row from the sums staged in LDS where they are: the same doubles, the same comparisons)
+                const int ik = cdfTop ? find_cdf(s_cdfLevel, p.nz, 1, rn) : find_cdf(p.voxelCDF + ((long long)p.nx - 1) + (long long)p.nx * (p.ny - 1), p.nz, nxy, rn);
+                const int ij = cdfTop ? find_cdf(s_cdfRow + p.ny * (ik - 1), p.ny, 1, rn) : find_cdf(p.voxelCDF + ((long long)p.nx - 1) + nxy * (ik - 1), p.ny, p.nx, rn);
                 const int ii = find_cdf(p.voxelCDF + (long long)p.nx * ((ij - 1) + (long long)p.ny * (ik - 1)), p.nx, 1, rn);
                 uint32_t r1[4];
                 philox4x32_10(0u, 1u, idLo, idHi, p.seedLo, p.seedHi, r1);
@@ -432,8 +469,8 @@ trace_block_kernel(const DevParams p) {
               ix = min((int)((px - p.x0) * p.invDX), p.nx - 1);
               iy = NOY ? 0 : min((int)((py - p.y0) * p.invDY), p.ny - 1);
             } else {
-              ix = find_cell(s_edge, p.nx, px);
-              iy = NOY ? 0 : find_cell(s_edge + offY, p.ny, py);
+              ix = NEAR ? locate_near_uniform(s_edge, p.nx, p.x0, p.invCellX, px) : find_cell(s_edge, p.nx, px);
+              iy = NOY ? 0 : (NEAR ? locate_near_uniform(s_edge + offY, p.ny, p.y0, p.invCellY, py) : find_cell(s_edge + offY, p.ny, py));
             }
             if (!EMIT) {
               pz = p.zLaunch; iz = p.izLaunch;
@@ -472,7 +509,7 @@ trace_block_kernel(const DevParams p) {
         // its cell, from the position (the periodic fold moves the position into the domain)
         {
           const double xw = px, yw = py;
-          iz = locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, pz);
+          iz = NEAR ? locate_near_uniform(s_edge + offZ, p.nz, p.z0, invDz, pz) : locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, pz);
           ix = locX(xw, (spans & 1u) != 0);
           iy = locY(yw, (spans & 2u) != 0);
         }
@@ -482,10 +519,10 @@ trace_block_kernel(const DevParams p) {
         int c = 0;  // component pick :759-760 (findIndex over [0, cumExt(:)]), uniform = slot Z of the leg's block
         if (nc > 1) {
           for (int k = 0; k < nc - 1; k++)
-            if (uZ >= cumAt(k * nvox + cell)) c = k + 1;
+            if (uZ >= cumAt(k, cell)) c = k + 1;
         }
-        float ssa = ssaAt(c * nvox + cell);
-        int pfEntry = pfiAt(c * nvox + cell);
+        float ssa = ssaAt(c, cell);
+        int pfEntry = pfiAt(c, cell);
         // A collision point within an ulp of a face of its block can be located next door -- harmless (the deposit and the
         // phase function of a cell an ulp away) unless next door is vacuum, where nothing collides: booked there the photon
         // would lose its whole weight (the host stores a single-scattering albedo of 0 where there is no extinction; the
@@ -498,10 +535,10 @@ trace_block_kernel(const DevParams p) {
           c = 0;
           if (nc > 1) {
             for (int k = 0; k < nc - 1; k++)
-              if (uZ >= cumAt(k * nvox + cell)) c = k + 1;
+              if (uZ >= cumAt(k, cell)) c = k + 1;
           }
-          ssa = ssaAt(c * nvox + cell);
-          pfEntry = pfiAt(c * nvox + cell);
+          ssa = ssaAt(c, cell);
+          pfEntry = pfiAt(c, cell);
         }
         if (DEBUG) countCrossings(px, py, iz);  // (after the fold of the look-ups above: px, py are the collision point)
         if (ssa < 1.0f) {  // absorption :765-771
@@ -613,13 +650,13 @@ trace_block_kernel(const DevParams p) {
           if (jy >= p.ny) { jy = 0; py -= p.Ly; if (DEBUG) dbgY -= p.ny; }            // periodic y :1790-1796: continue in the next image
           else if (jy < 0) { jy = p.ny - 1; py += p.Ly; if (DEBUG) dbgY += p.ny; }
           jx = inRangeX(locX(xw, (spans & 1u) != 0), rx);
-          jz = inRangeX(locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
+          jz = inRangeX(NEAR ? locate_near_uniform(s_edge + offZ, p.nz, p.z0, invDz, zw) : locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
         } else {
           jx = dx >= 0.0f ? (int)(rx >> 16) : (int)(rx & 0xffffu) - 1;
           if (jx >= p.nx) { jx = 0; px -= p.Lx; if (DEBUG) dbgX -= p.nx; }            // periodic x :1782-1788
           else if (jx < 0) { jx = p.nx - 1; px += p.Lx; if (DEBUG) dbgX += p.nx; }
           jy = NOY ? 0 : inRangeX(locY(yw, (spans & 2u) != 0), ry);
-          jz = inRangeX(locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
+          jz = inRangeX(NEAR ? locate_near_uniform(s_edge + offZ, p.nz, p.z0, invDz, zw) : locate_z(s_edge + offZ, p.nz, zRegular, p.z0, invDz, zw), rz);
         }
         // (every axis the block left spans has just been folded -- it cannot be the axis crossed, a spanning block has no
         // face there.  The bits must not outlive the fold: a lane that has just WRAPPED stands on the domain boundary, and

@@ -83,6 +83,7 @@ struct DevParams {
   const float *extWalk;           // [nvox] what the photons' walk reads: ext, with the sign bit set in the cells outside their brick column's range (fly off: ext itself)
   const float *bgVal;             // [nz] background extinction of every layer (its most common value)
   int xyNearUniform;              // x and y edges equally spaced to 1e-6 of a cell: cell guess by division, table decides
+  int zNearUniform;               // the same for z (block walk, SIMPLE = 3)
   double invLx, invLy;            // 1 / domain length
   double invCellX, invCellY;      // nx / Lx, ny / Ly
   const double *edges;            // [xe(nx+1) | ye(ny+1) | ze(nz+1)]
@@ -112,6 +113,9 @@ struct DevParams {
                                   // flag bit 0 / 1: the block spans the whole periodic x / y axis (no face on it)
   const uint16_t *blockOf;        // [nvox] block of each cell
   const float *blockExt;          // [nBlocks] extinction of each block (what LDS holds when the per-cell optics stay in global memory)
+  const float *blockSsa, *blockCum;  // [nc][nBlocks] optics per block, where every block is uniform in them too (trace_block_kernel<..., OPT = 2>)
+  const uint16_t *blockPfi;
+  int cdfTopLds;                  // thermal source, block walk: the level and row sums of the emission CDF are staged in LDS
   int crossThreshold;             // lanes queued before block crossings are served
   // inverse phase-function tables (set_inverse_table)
   const float *tables;            // all components, concatenated, entry-major

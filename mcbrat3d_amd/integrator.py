@@ -233,7 +233,8 @@ class Integrator:
         return {"layerSkip": bool(m & 1), "blockWalk": bool(m & 2), "clearAirFlight": bool(m & 4),
                 # tallies private to a workgroup in LDS; the wide plan: one workgroup of 1024 lanes per compute unit owns its LDS;
                 # the block walk with the per-cell optics left in global memory (extinction per block in LDS)
-                "privateTallies": bool(m & 64), "widePlan": bool(m & 16), "opticsInGlobalMemory": bool(m & 32)}
+                "privateTallies": bool(m & 64), "widePlan": bool(m & 16), "opticsInGlobalMemory": bool(m & 32),
+                "opticsPerBlock": bool(m & 128), "emissionCdfTopInLds": bool(m & 256)}
 
     def badPhotons(self):
         """Photons dropped by a loop bound of the kernels since this integrator was created (the reference's nBad, :562-563)."""

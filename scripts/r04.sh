@@ -131,6 +131,30 @@ step_pmc_lw() {  # counters of config 4's kernel (one wavelength's launch), wide
   MCBRAT_WIDE=0 bash scripts/pmc_profile.sh lw r04/pmc_lw_nowide > $OUT/pmc_lw_nowide.log 2>&1
   tail -3 $OUT/pmc_lw.log | cut -c1-200
 }
+step_lw_quick() {  # config 4: bench line without the CPU leg, and one wavelength's launch alone
+  local f=$OUT/bench_lw_quick_$(ts)
+  python bench.py --workload homogLW20x16 --steps 5 --warmup 1 --no-cpu-baseline > $f.json 2> $f.err; local rc=$?
+  python - "$f.json" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r=d["roofline"]
+print("LW value %.4g ms/step %.3f kernel_ms %.3f kernel %s bad %s" % (d["value"], d["ms_per_step"], r["kernel_ms_per_launch"], r["kernel"][:200], d["config"].get("bad_photons")))
+PY
+  THR=16 LTHR=32 timeout -k 10 120 python scripts/lw_probe.py 62500 100 2>&1 | grep "counters False" | tail -1
+  echo "lw_quick rc=$rc out=$f.json"
+}
+step_lw_sweep() {  # config 4, one wavelength's launch (6.25e6 photons as 100 batches): thresholds of the wide plan's kernel; stamps
+  local log=$OUT/lw_sweep_$(ts).log
+  for thr in 4 8 16 32; do for lthr in 16 32 48 64; do
+    echo "== THR=$thr LTHR=$lthr" >> $log
+    THR=$thr LTHR=$lthr timeout -k 10 120 python scripts/lw_probe.py 62500 100 2>&1 | grep "counters False" | tail -1 >> $log
+  done; done
+  echo "== stamps" >> $log
+  MCBRAT_LIB=$ROOT/ab/libmcbrat_stamps.so timeout -k 10 120 python scripts/lw_probe.py 62500 100 >> $log 2>&1
+  grep -A1 "^== " $log | grep -v "^--" | paste - - | cut -c1-160
+  grep "stamp\|lanes per" $log | cut -c1-200
+  echo "lw_sweep log=$log"
+}
 step_ab() {  # A/B of libraries in ab/: scripts/r04.sh ab <case> <thr> lib1 lib2 ...  (case: step | landsat | radar)
   local case=$1 thr=$2; shift 2
   local log=$OUT/ab_${case}_$(ts).log

@@ -147,6 +147,44 @@ def test_block_walk_with_two_components(M):
     integ.finalize()
 
 
+@pytest.mark.parametrize("which", ["slabs, 0.1 km cells", "thermal 8x8x8 (config 4's kind)", "thermal 12x12x12, wide plan"])
+def test_near_uniform_specialisation_equals_the_general_kernel(M, which, monkeypatch):
+    """SIMPLE = 3: a grid whose spacing is not exactly representable in single precision (0.1 km cells: config 4) is NOT
+    equally spaced by the reference's own test (new_Integrator :140, :163-181), yet equally spaced to 1e-6 of a cell.  The
+    instantiation that decides this at compile time must find exactly the cells the general one finds (division + table check
+    against bisection): moment arrays bit for bit, with the specialisation switched off (MCBRAT_NO_SIMPLE3) as the reference run."""
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    if which.startswith("slabs"):
+        ext = np.zeros((10, 6, 12))
+        ext[:5], ext[5:] = 4.0, 25.0
+        case = dict(name="slabs01", xe=0.1 * np.arange(11), ye=0.1 * np.arange(7), ze=0.1 * np.arange(13), albedo=0.3,
+                    components=[dict(ext=ext, ssa=np.full_like(ext, 0.97), pfIndex=np.ones(ext.shape, np.int32), legendre=[cases.hg_legendre(0.8, 32)])])
+        lw, tuning = False, dict(blockWalk=1)
+    else:
+        case = cases.homog_lw(n=12 if "wide" in which else 8)
+        lw, tuning = True, dict(blockWalk=1, privateTallies=6 if "wide" in which else 1)
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("MCBRAT_NO_SIMPLE3", "1")
+        dom = cases.product_domain(case)
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True, LW_flag=1.0 if lw else -1.0)
+        integ.setTuning(eventThreshold=16, **tuning)
+        if lw:
+            w = M.new_Weights(dom.numX, dom.numY, dom.numZ)
+            M.emission_weighting(dom, w, case["sfc_temp"])
+            photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 9)
+        else:
+            photons = M.new_PhotonStream(0.55, 20.0, numberOfPhotons=10 ** 9)
+        integ.resetMoments()
+        integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, 30000, 4)
+        out.append(integ.moments().copy())
+        assert integ.walkMode()["blockWalk"]
+        integ.finalize()
+    assert np.array_equal(out[0], out[1])
+
+
 def test_xz_specialisation_equals_the_3d_kernel(M):
     """A domain one cell wide in y runs the instantiation with the y position compiled out (SIMPLE = 2).  The same
     medium cut into TWO rows in y runs the 3-D instantiation on the very same photons (same Philox streams, same x-z

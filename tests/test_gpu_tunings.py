@@ -54,7 +54,7 @@ def test_random_tunings_give_the_same_histories(M, seed):
     # optical grid beside them (4) or left in global memory (5: for the block walk, extinction per block in LDS) -- which
     # the library chooses by itself only for tally slabs too large to share a compute unit (config 4's 70 KB)
     queues = dict(jumpThreshold=int(rng.choice([1, 8, 24])), crossThreshold=int(rng.choice([1, 8, 24])))  # (by name: mcbrat_set_option)
-    layout = dict(privateTallies=int(rng.choice([0, 1, 4, 5])), brickLayout=int(rng.integers(0, 2)))
+    layout = dict(privateTallies=int(rng.choice([0, 1, 4, 5, 6])), brickLayout=int(rng.integers(0, 2)))
     if layout["privateTallies"] >= 4:
         layout.update(blockSize=0, brickLayout=0)
     for name, walk, base_tuning, tuning in (
@@ -65,7 +65,7 @@ def test_random_tunings_give_the_same_histories(M, seed):
             ("layers, wide plan", dict(layerSkip=2, blockWalk=0, brickLayout=0), dict(eventThreshold=16, privateTallies=0),
              {**{k: v for k, v in sched.items() if k != "blockSize"}, "privateTallies": 5}),
             ("block walk", dict(blockWalk=2), dict(eventThreshold=16),
-             {**{k: v for k, v in sched.items() if k != "blockSize"}, **queues, "privateTallies": int(rng.choice([1, 4, 5]))})):
+             {**{k: v for k, v in sched.items() if k != "blockSize"}, **queues, "privateTallies": int(rng.choice([1, 4, 5, 6]))})):
         base = _run(M, case, mu0, phi0, rr, walk, base_tuning)
         got = _run(M, case, mu0, phi0, rr, walk, tuning)
         for f in base[0].dtype.names:
@@ -105,7 +105,7 @@ def test_random_tunings_give_the_same_histories_thermal_source(M, seed):
     case["lambda_um"] = float(rng.uniform(6.0, 14.0))
     sched = dict(eventThreshold=int(rng.choice([1, 4, 16, 40, 64])), launchThreshold=int(rng.choice([1, 8, 48])),
                  surfaceThreshold=int(rng.choice([1, 12, 32])), maxBatchesInFlight=int(rng.choice([0, 1, 2])))
-    wide = dict(privateTallies=int(rng.choice([4, 5])))  # the wide plan (config 4's), see above
+    wide = dict(privateTallies=int(rng.choice([4, 5, 6])))  # the wide plan (config 4's), see above
     for name, walk, plans in (("face by face", dict(layerSkip=0, blockWalk=0, privateTallies=0), [wide]),
                               ("layers + flight", dict(layerSkip=3, blockWalk=0, privateTallies=0), []),  # (the wide plan carries no flight)
                               # (privateTallies = 5: with the grid in LDS too -- 4 -- the walk is the face-by-face one)
