@@ -204,7 +204,9 @@ int mcbrat_wait_stream(mcbrat_ctx *ctx, void *hipStream);
  * mcbrat_set_async on each of them, mcbrat_chain_after(ctx, previous) orders the device instead: the finish kernels (and the
  * reset) of ctx's NEXT call run after everything `previous` has enqueued so far, while the tracing kernels of the two contexts
  * overlap -- the tail of one wavelength's launch is filled by the next wavelength's photons.  Results are bitwise those of
- * synchronous calls in the same order.  Both contexts must live on the same device; `previous` must outlive the chained call. */
+ * synchronous calls in the same order.  Both contexts must live on the same device.  "So far" is fixed when this function is
+ * called: ctx records an event of its OWN on `previous`'s stream and waits for that, so `previous` may be destroyed, or go on
+ * to further calls, before ctx's next one. */
 int mcbrat_chain_after(mcbrat_ctx *ctx, mcbrat_ctx *previous);
 /* Tuning knobs (negative = leave unchanged): workgroups per CU (0 = occupancy query), number of
  * walking lanes below which a wave serves its waiting lanes (0 = choose by timing short trial

@@ -547,9 +547,13 @@ trace_block_kernel(const DevParams p) {
           if (DEBUG) cAbs++;
         }
         if (p.useRR && w < 0.5f) {  // Russian roulette :805-811, RussianRouletteW = 1
-          uint32_t r1[4];
-          philox4x32_10(event, 1u, idLo, idHi, p.seedLo, p.seedHi, r1);
-          if (u01(r1[1]) >= w) { w = 0.0f; if (DEBUG) cKill++; }
+          float uR = uZ;  // one component: Z decides nothing at the component pick and serves here (no second block; mcbrat_kernels.hip)
+          if (nc != 1) {  // (wave-uniform; compile time in the SIMPLE instantiations)
+            uint32_t r1[4];
+            philox4x32_10(event, 1u, idLo, idHi, p.seedLo, p.seedHi, r1);
+            uR = u01(r1[1]);
+          }
+          if (uR >= w) { w = 0.0f; if (DEBUG) cKill++; }
           else { w = 1.0f; if (DEBUG) cSurv++; }
         }
         STAMP(2);

@@ -1014,7 +1014,7 @@ int64_t orc_compute_rt_intensity(const orc_problem *P, const orc_source *S, orc_
     int fate = -1;
     float fateWeight = 0.0f;
     for (;;) { /* scatteringLoop :548 */
-      if (R->mode == 1) philox_next_event(R); /* event e: block 0 = [tau, X, Y, Z], block 1 = [-, roulette, -, -]; scattering angle = X, azimuth = Y, component = Z */
+      if (R->mode == 1) philox_next_event(R); /* event e: block 0 = [tau, X, Y, Z], block 1 = [-, roulette, -, -] (one component: roulette = Z); scattering angle = X, azimuth = Y, component = Z */
       float u = draw(R, 0, 0);
       float tauToTravel = -logf(u > FLT_MIN ? u : FLT_MIN); /* :554 */
       cnt.legs++;
@@ -1114,7 +1114,9 @@ int64_t orc_compute_rt_intensity(const orc_problem *P, const orc_source *S, orc_
           add_intensity(P, I, contributions, xIndexF, yIndexF, component, intensity, intensityByComponent);
         }
         if (P->useRussianRoulette && photonWeight < RussianRouletteW / 2.0f) { /* :805-811 */
-          if (draw(R, 1, 1) >= photonWeight / RussianRouletteW) /* block 1 elem 1 */ { photonWeight = 0.0f; cnt.rouletteKills++; }
+          /* Philox mode: block 1 elem 1 -- or, in a domain of ONE component, elem 3 of the leg's own block (Z: the uniform of the
+           * component pick, which with one component decides nothing), so that the kernels need no second block for it */
+          if (draw(R, P->nc == 1 ? 0 : 1, P->nc == 1 ? 3 : 1) >= photonWeight / RussianRouletteW) { photonWeight = 0.0f; cnt.rouletteKills++; }
           else { photonWeight = RussianRouletteW; cnt.rouletteSurvivals++; }
         }
         if (photonWeight <= FLT_MIN) { fate = 2; break; } /* :812 */
