@@ -37,9 +37,12 @@ step_poison_all() {  # the rest of the suite under the audit build
 step_base() {  # development timing of the three workloads (not the judged bench)
   local log=$OUT/base_$(ts).log
   { timeout -k 10 200 python scripts/quick_bench.py --case step --thr 16 --reps 5 --counters
-    MCBRAT_LIB=$ROOT/ab/libmcbrat_r03.so MCBRAT_LIB_OLD=1 timeout -k 10 200 python scripts/quick_bench.py --case landsat --ppb 1000000 --batches 100 --thr 20 --reps 3
-    MCBRAT_LIB=$ROOT/ab/libmcbrat_r03.so MCBRAT_LIB_OLD=1 timeout -k 10 200 python scripts/quick_bench.py --case radar --ppb 1000000 --batches 100 --thr 24 --reps 3; } > $log 2>&1
-  grep "^case\|lanes/phase" $log | cut -c1-330
+    for lib in ab/libmcbrat_r03.so mcbrat3d_amd/libmcbrat_hip.so; do
+      echo "== $lib"
+      MCBRAT_LIB=$ROOT/$lib MCBRAT_LIB_OLD=1 timeout -k 10 200 python scripts/quick_bench.py --case landsat --ppb 1000000 --batches 100 --thr 20 --reps 3
+      MCBRAT_LIB=$ROOT/$lib MCBRAT_LIB_OLD=1 timeout -k 10 200 python scripts/quick_bench.py --case radar --ppb 1000000 --batches 100 --thr 24 --reps 3
+    done; } > $log 2>&1
+  grep "^==\|^opts\|^case\|lanes/phase" $log | cut -c1-330
   echo "base log=$log"
 }
 step_bench() {  # the judged line (step cloud + 128x128x64 secondary)
