@@ -704,15 +704,24 @@ int launch_trace_t(mcbrat_ctx *c, DevParams &p, size_t lds, int nBatches) {
   if constexpr (BLOCK == 256 && PRIV == 0 && !BRICK && !DBG && !INTEN) {
     // the large flux runs: dense grid in global memory, collision records (nc <= 2), layer-skipping walk, albedo
     // surface -- with the walk's spacing flags decided at compile time too (SPEC, mcbrat_kernels.hip)
-    if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk && !p.zRegularWalk)
-      return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 3>(c, p, lds, nBatches)
-                             : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 3>(c, p, lds, nBatches);
-    if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && p.xyRegularWalk == p.zRegularWalk) {
-      if (p.xyRegularWalk)
-        return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 2>(c, p, lds, nBatches)
-                               : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 2>(c, p, lds, nBatches);
-      return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, 1>(c, p, lds, nBatches)
-                             : launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 1>(c, p, lds, nBatches);
+    // A solar run with roulette (every bench workload) also has its component count and the roulette decided at compile
+    // time (SPEC bits 2-3 and 4); without roulette it runs the general kernel.
+    if (p.rec != nullptr && p.layerSkip && p.fly && p.surfNumX == 0 && (p.xyRegularWalk || !p.zRegularWalk)) {
+      const int walk = p.xyRegularWalk ? (p.zRegularWalk ? 2 : 3) : 1;
+      if (c->srcKind != 0) {
+        if (walk == 1) return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 1>(c, p, lds, nBatches);
+        if (walk == 2) return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 2>(c, p, lds, nBatches);
+        return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, true, 3>(c, p, lds, nBatches);
+      }
+      if (p.useRR && (p.nc == 1 || p.nc == 2)) {
+        const int spec = walk | p.nc << 2 | 16;
+        switch (spec) {
+#define MCBRAT_SPEC_CASE(S) case S: return launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false, S>(c, p, lds, nBatches)
+          MCBRAT_SPEC_CASE(1 | 1 << 2 | 16); MCBRAT_SPEC_CASE(2 | 1 << 2 | 16); MCBRAT_SPEC_CASE(3 | 1 << 2 | 16);
+          MCBRAT_SPEC_CASE(1 | 2 << 2 | 16); MCBRAT_SPEC_CASE(2 | 2 << 2 | 16); MCBRAT_SPEC_CASE(3 | 2 << 2 | 16);
+#undef MCBRAT_SPEC_CASE
+        }
+      }
     }
   }
   return c->srcKind == 0 ? launch_trace_e<BLOCK, TBL, PRIV, BRICK, DBG, INTEN, false>(c, p, lds, nBatches)
