@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: steps run on the GPU box, selected by name (one script instead of one file per gpurun call):
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash scripts/r04.sh tests poison base'
-# steps: tests bounds poison poison_all base bench bench_lw lw_ab rates soak profiles parity ab
+# steps: tests bounds poison poison_all base bench bench_lw lw_ab rates soak profiles benches parity ab
 # Every step writes under gpurun_out/r04/ with a time stamp in the file name, so that a failing log is never overwritten.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -81,7 +81,8 @@ step_soak() {  # the random differential tests with more seeds (SOAK seeds each,
   done
   return 0
 }
-step_profiles() {  # the measurement record of the shipped kernels: bench lines, rocprofv3 kernel stats, PMC passes (-> profiles/r04_*)
+step_benches() {  # the bench lines of the record; run AFTER profiles/pmc_shipped.json has been regenerated from this library's counters
+                 # (profiles -> scripts/r04_collect.sh -> benches -> collect again), or they carry `counters_stale`
   local P=$OUT/prof; mkdir -p $P
   python bench.py --pipelined-extra > $P/bench_stepcloud.json 2> $P/bench_stepcloud.err; echo "bench step rc=$?"
   python bench.py --workload landsatLike128 --steps 5 --warmup 1 > $P/bench_landsat.json 2> $P/bench_landsat.err; echo "bench landsat rc=$?"
@@ -89,6 +90,9 @@ step_profiles() {  # the measurement record of the shipped kernels: bench lines,
   python bench.py --workload radarLike128 --steps 3 --warmup 1 --no-cpu-baseline > $P/bench_radar.json 2> $P/bench_radar.err; echo "bench radar rc=$?"
   python bench.py --block-walk 0 --no-cpu-baseline --no-secondary > $P/bench_stepcloud_facebyface.json 2> $P/bench_fbf.err; echo "bench fbf rc=$?"
   BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-secondary --steps 20 > $P/bench_stepcloud_rccl1.json 2> $P/bench_rccl1.err; echo "bench rccl rc=$?"
+}
+step_profiles() {  # the measurement record of the shipped kernels: rocprofv3 kernel stats, PMC passes (-> profiles/r04_*); then `benches`
+  local P=$OUT/prof; mkdir -p $P
   ( cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_step -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --event-threshold 16 > $P/stats_step.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_landsat -- python3 $ROOT/bench.py --workload landsatLike128 --steps 5 --warmup 1 --no-cpu-baseline --event-threshold 20 > $P/stats_landsat.log 2>&1
