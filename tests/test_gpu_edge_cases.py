@@ -51,6 +51,23 @@ def test_tiny_and_ragged_photon_counts(M, n):
     assert abs(last["meanFluxUp"] + last["meanFluxDown"] + last["meanFluxAbsorbed"] - 1.0) < 0.05 + 2.0 / n
 
 
+@pytest.mark.parametrize("first", [2 ** 32 - 700, 2 ** 40 + 12345])
+def test_photon_ids_beyond_32_bits(M, first):
+    """A production run of more than 4.3e9 photons crosses 2^32 photon ids: the id is the Philox counter's low and high word
+    (getRandomReal's stream position in the reference: one stream per process, RandomNumbersForMC.f95:277-292).  A batch
+    that straddles the boundary, and one far beyond it, against the oracle started at the same id."""
+    case = cases.step_cloud(0.99)
+    n = 2000
+    done, st, last, _ = _run(M, case, 1.0, 0.0, n, 1, first=first)
+    ref = _oracle(case, 1.0, 0.0, n, first=first)
+    assert done == n and st["totalPhotons"] == n
+    assert np.allclose(last["fluxUp"][:, 0], ref["fluxUp"], atol=32.0 / n * 2.01 + 1e-5)   # (two flipped histories at most)
+    assert np.allclose(last["fluxDown"][:, 0], ref["fluxDown"], atol=32.0 / n * 2.01 + 1e-5)
+    # ... and they are other photons than those of ids 0 .. n-1
+    base = _run(M, case, 1.0, 0.0, n, 1, first=0)[2]
+    assert not np.array_equal(base["fluxUp"], last["fluxUp"])
+
+
 def test_more_batches_than_workgroups(M):
     """3000 batches of 512 photons: workgroups loop over units; moments fold every batch."""
     case = cases.plane_parallel(ssa=0.9)
