@@ -1,0 +1,148 @@
+"""Known answers that come from physics, not from the oracle: the closed forms a plane-parallel medium has.  The reference
+holds no tests (its authors validated "by eye against analytic / plane-parallel results"); these are
+the three such results that are exact, applied to the ORACLE on the CPU and -- marked gpu -- to the product through the
+C ABI, so that the two are also held to something neither of them wrote.
+
+1. Beer-Lambert: omega0 = 0, sun at mu0: the surface receives exp(-tau / mu0), nothing leaves the top
+   (accumulateExtinctionAlongPath, src/opticalProperties.f95:1696-1812, and nothing else).
+2. Conservation: omega0 = 1 over a surface of albedo 1: every photon leaves through the top, with weight exactly 1.
+3. Isothermal emission: omega0 = 0, black surface at the temperature of the layer: the layer emits 4 pi B kappa dz per
+   area and the surface pi B (emission_weightingNEW, src/emissionAndBroadBandWeights.f95:424-550).  The top receives
+   pi B -- the surface's part attenuated by the flux transmission 2 E3(tau), the layer's own pi B (1 - 2 E3(tau)); Kirchhoff
+   -- and the surface receives the layer's part only (space sends nothing).  As fractions of the emitted power, with
+   e = 1 / (1 + 4 tau): atmosphere 4 tau e, up = e, down = e (1 - 2 E3(tau)), net absorbed by the layer -e (1 - 2 E3(tau))
+   (LW_flag > 0 tallies emission as negative absorption, Integrators/monteCarloRadiativeTransfer.f95:504-508).  This
+   exercises the power split, the launch positions, the isotropic and the Lambertian launch directions and the free
+   paths together.
+"""
+import numpy as np
+import pytest
+from scipy.special import expn
+
+from tests import cases
+
+SEED = 20241005
+
+
+def _sigma(p, n):
+    return float(np.sqrt(max(p * (1.0 - p), 1e-12) / n))
+
+
+def slab(tau, ssa, albedo=0.0, nz=8):
+    case = cases.plane_parallel(ssa=ssa, tau=tau, nz=nz, g=0.0, nleg=2)
+    case["albedo"] = albedo
+    return case
+
+
+def isothermal(tau, n=6, temp=285.0):
+    depth = 0.1 * n
+    return cases.homog_lw(n=n, ext=tau / depth, ssa=0.0, g=0.0, nleg=2, temp=temp, sfc_temp=temp, albedo=0.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the oracle (CPU)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tau,mu0", [(0.5, 1.0), (2.0, 0.5), (1.0, 0.2)])
+def test_oracle_beer_lambert(tau, mu0):
+    from oracle import oracle as O
+    n = 100000
+    P = cases.oracle_problem(slab(tau, 0.0), nsteps=101)
+    r = O.compute_radiative_transfer(P, O.solar_source(mu0, 40.0), O.philox_rng(SEED, 0), n)
+    t = float(np.exp(-tau / mu0))
+    assert r["meanFluxUp"] == 0.0
+    assert abs(r["meanFluxDown"] - t) < 4.5 * _sigma(t, n) + 1e-6
+    assert abs(r["meanFluxAbsorbed"] - (1.0 - t)) < 4.5 * _sigma(t, n) + 1e-6
+
+
+def test_oracle_conserves_energy_over_a_white_surface():
+    from oracle import oracle as O
+    n = 20000
+    P = cases.oracle_problem(slab(1.0, 1.0, albedo=1.0), nsteps=101)
+    r = O.compute_radiative_transfer(P, O.solar_source(0.6, 0.0), O.philox_rng(SEED, 0), n)
+    assert abs(r["meanFluxUp"] - 1.0) < 2e-6 and abs(r["meanFluxAbsorbed"]) < 2e-6
+    # (the surface sees every photon that reaches it, each time: more than the direct beam)
+    assert r["meanFluxDown"] > float(np.exp(-1.0 / 0.6))
+
+
+@pytest.mark.parametrize("tau", [0.25, 1.0, 3.0])
+def test_oracle_isothermal_layer_over_a_black_surface(tau):
+    from oracle import oracle as O
+    n = 100000
+    case = isothermal(tau)
+    P = cases.oracle_problem(case, nsteps=101, lw_flag=1.0)
+    vw, frac, _ = O.emission_weighting(P, case["temps"].transpose(2, 1, 0).reshape(-1), case["lambda_um"], case["sfc_temp"])
+    assert abs(frac - 4.0 * tau / (1.0 + 4.0 * tau)) < 1e-6
+    r = O.compute_radiative_transfer(P, O.EmissionSource(vw, frac), O.philox_rng(SEED, 0), n)
+    e = 1.0 / (1.0 + 4.0 * tau)
+    d = e * (1.0 - 2.0 * float(expn(3, tau)))
+    assert abs(r["meanFluxUp"] - e) < 4.5 * _sigma(e, n)
+    assert abs(r["meanFluxDown"] - d) < 4.5 * _sigma(d, n)
+    assert abs(r["meanFluxAbsorbed"] + d) < 4.5 * (_sigma(e, n) + _sigma(d, n))
+    # ... and level by level: the layers cool to space from the top; next to the black surface at their own temperature
+    # they are nearly in balance
+    prof = np.asarray(r["absorbedProfile"], np.float64)
+    assert prof[-1] < 0.0 and abs(prof[0]) < abs(prof[-1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the product, through the C ABI
+# ---------------------------------------------------------------------------------------------------------------------
+def _solar(case, mu0, phi0, n, rr=True):
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=101, useRayTracing=True, useRussianRoulette=rr)
+    photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
+    integ.resetMoments()
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n) == n
+    res = integ.reportResults()
+    bad = integ.badPhotons()
+    integ.finalize()
+    assert bad == 0
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tau,mu0", [(0.5, 1.0), (2.0, 0.5), (1.0, 0.2)])
+def test_product_beer_lambert(tau, mu0):
+    n = 1000000
+    r = _solar(slab(tau, 0.0), mu0, 40.0, n)
+    t = float(np.exp(-tau / mu0))
+    assert r["meanFluxUp"] == 0.0
+    assert abs(r["meanFluxDown"] - t) < 4.5 * _sigma(t, n) + 1e-6
+    assert abs(r["meanFluxAbsorbed"] - (1.0 - t)) < 4.5 * _sigma(t, n) + 1e-6
+
+
+@pytest.mark.gpu
+def test_product_conserves_energy_over_a_white_surface():
+    r = _solar(slab(1.0, 1.0, albedo=1.0), 0.6, 0.0, 200000)
+    assert abs(r["meanFluxUp"] - 1.0) < 2e-6 and abs(r["meanFluxAbsorbed"]) < 2e-6
+    assert r["meanFluxDown"] > float(np.exp(-1.0 / 0.6))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tau", [0.25, 1.0, 3.0])
+def test_product_isothermal_layer_over_a_black_surface(tau):
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    n = 1000000
+    case = isothermal(tau)
+    dom = cases.product_domain(case)
+    nx = len(case["xe"]) - 1
+    w = M.new_Weights(nx, nx, nx)
+    M.emission_weighting(dom, w, case["sfc_temp"])
+    assert abs(w.fracAtmsPower - 4.0 * tau / (1.0 + 4.0 * tau)) < 1e-6
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=101, useRayTracing=True, useRussianRoulette=True, LW_flag=1.0)
+    photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 12)
+    integ.resetMoments()
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n) == n
+    r = integ.reportResults()
+    assert integ.badPhotons() == 0
+    integ.finalize()
+    e = 1.0 / (1.0 + 4.0 * tau)
+    d = e * (1.0 - 2.0 * float(expn(3, tau)))
+    assert abs(r["meanFluxUp"] - e) < 4.5 * _sigma(e, n)
+    assert abs(r["meanFluxDown"] - d) < 4.5 * _sigma(d, n)
+    assert abs(r["meanFluxAbsorbed"] + d) < 4.5 * (_sigma(e, n) + _sigma(d, n))
