@@ -14,6 +14,11 @@ C ABI, so that the two are also held to something neither of them wrote.
    (LW_flag > 0 tallies emission as negative absorption, Integrators/monteCarloRadiativeTransfer.f95:504-508).  This
    exercises the power split, the launch positions, the isotropic and the Lambertian launch directions and the free
    paths together.
+4. Multiple scattering: a slab that scatters isotropically, against the numerical solution of its integral equation
+   (Schwarzschild-Milne: S(t) = omega [ e^(-t/mu0) / (4 pi mu0) + 1/2 int S(t') E1(|t - t'|) dt' ], fluxes 2 pi int S E2):
+   piecewise-constant source on 1500 cells with the kernel integrated exactly over every cell -- converged to 10^-6, and
+   conserving energy to 10^-6 at omega = 1 by itself.  Holds the collision loop, the scattering-angle tables, the
+   direction algebra and the roulette (computeRT :703-821) to transport theory.
 """
 import numpy as np
 import pytest
@@ -39,9 +44,48 @@ def isothermal(tau, n=6, temp=285.0):
     return cases.homog_lw(n=n, ext=tau / depth, ssa=0.0, g=0.0, nleg=2, temp=temp, sfc_temp=temp, albedo=0.0)
 
 
+def isotropic_slab(b, omega, mu0, cells=1500):
+    """(reflected, diffusely transmitted, directly transmitted) share of the incident flux for a slab of optical depth b
+    that scatters isotropically with single-scattering albedo omega, sun at mu0, black surface."""
+    h = b / cells
+    edges = np.arange(cells + 1) * h
+    tc = edges[:-1] + 0.5 * h
+    kern = 0.5 * np.abs(expn(2, np.abs(tc[:, None] - edges[None, :-1])) - expn(2, np.abs(tc[:, None] - edges[None, 1:])))
+    kern[np.arange(cells), np.arange(cells)] = 1.0 - expn(2, 0.5 * h)  # the cell around the point itself: 2 * 1/2 * (E2(0) - E2(h/2))
+    direct = (np.exp(-edges[:-1] / mu0) - np.exp(-edges[1:] / mu0)) / (4.0 * np.pi * h)  # cell mean of e^(-t/mu0) / (4 pi mu0)
+    src = np.linalg.solve(np.eye(cells) - omega * kern, omega * direct)
+    up = 2.0 * np.pi * float(np.sum(src * (expn(3, edges[:-1]) - expn(3, edges[1:]))))
+    down = 2.0 * np.pi * float(np.sum(src * (expn(3, b - edges[1:]) - expn(3, b - edges[:-1]))))
+    return up, down, float(np.exp(-b / mu0))
+
+
+SCATTERING_SLABS = [(1.0, 1.0, 1.0), (2.0, 0.9, 0.5), (0.5, 1.0, 0.3), (4.0, 0.6, 0.8)]
+
+
+def test_the_integral_equation_solver_conserves_energy_and_has_converged():
+    for b, mu0 in ((1.0, 1.0), (0.5, 0.3), (3.0, 0.7)):
+        up, down, direct = isotropic_slab(b, 1.0, mu0)
+        assert abs(up + down + direct - 1.0) < 3e-6
+        assert np.allclose(isotropic_slab(b, 1.0, mu0, cells=600)[:2], (up, down), atol=5e-6)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the oracle (CPU)
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,omega,mu0", SCATTERING_SLABS)
+def test_oracle_isotropic_scattering_against_the_integral_equation(b, omega, mu0):
+    from oracle import oracle as O
+    n = 200000
+    P = cases.oracle_problem(slab(b, omega, nz=16), nsteps=9001)
+    r = O.compute_radiative_transfer(P, O.solar_source(mu0, 75.0), O.philox_rng(SEED, 0), n)
+    up, down, direct = isotropic_slab(b, omega, mu0)
+    # (a photon's weight is not 0 / 1 when omega < 1, and roulette adds variance: the binomial sigma is a bound from below;
+    # 6 of them is the tolerance -- 0.6 % of a flux of 0.3 at this sample size)
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - (down + direct)) < 6.0 * _sigma(down + direct, n)
+    assert abs(r["meanFluxAbsorbed"] - (1.0 - up - down - direct)) < 6.0 * _sigma(up, n) + 1e-6
+
+
 @pytest.mark.parametrize("tau,mu0", [(0.5, 1.0), (2.0, 0.5), (1.0, 0.2)])
 def test_oracle_beer_lambert(tau, mu0):
     from oracle import oracle as O
@@ -112,6 +156,28 @@ def test_product_beer_lambert(tau, mu0):
     assert r["meanFluxUp"] == 0.0
     assert abs(r["meanFluxDown"] - t) < 4.5 * _sigma(t, n) + 1e-6
     assert abs(r["meanFluxAbsorbed"] - (1.0 - t)) < 4.5 * _sigma(t, n) + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,omega,mu0", SCATTERING_SLABS)
+def test_product_isotropic_scattering_against_the_integral_equation(b, omega, mu0):
+    n = 4000000
+    case = slab(b, omega, nz=16)
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True)
+    photons = M.new_PhotonStream(mu0, 75.0, numberOfPhotons=10 ** 12)
+    integ.resetMoments()
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n) == n
+    r = integ.reportResults()
+    assert integ.badPhotons() == 0
+    integ.finalize()
+    up, down, direct = isotropic_slab(b, omega, mu0)
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)                       # (0.14 % of a flux of 0.3)
+    assert abs(r["meanFluxDown"] - (down + direct)) < 6.0 * _sigma(down + direct, n)
+    assert abs(r["meanFluxAbsorbed"] - (1.0 - up - down - direct)) < 6.0 * _sigma(up, n) + 1e-6
 
 
 @pytest.mark.gpu
