@@ -23,6 +23,8 @@ C ABI, so that the two are also held to something neither of them wrote.
    terms) against matrix doubling on 129 Gauss streams -- a second deterministic solver, written independently of the
    first and equal to it to 10^-6 where both apply -- for the phase function the reference SAMPLES, which is not quite
    the series it is given (`sampled_moments`; a property of the reference that the drop-in keeps, measured below).
+6. Thermal emission WITH scattering and a temperature profile: the integral equation again, with the source
+   (1 - omega) B(tau) + omega J and the black surface's 1/2 B_s E2: power split, top and surface fluxes.
 """
 import numpy as np
 import pytest
@@ -153,6 +155,45 @@ def hg_slab(tau, ssa, g, nleg, nz=16):
 HG_STREAMS = 129
 HG_SLABS = [(2.0, 0.95, 0.6, 48, 64), (1.0, 1.0, 0.85, 64, 124), (4.0, 0.9, 0.85, 64, 20), (18.0, 0.99, 0.85, 64, 64)]
 
+def planck(lambda_um, temp):
+    """Planck's function, arbitrary units (only ratios enter)."""
+    return 1.0 / (lambda_um ** 5 * np.expm1(14387.77 / (lambda_um * np.asarray(temp, np.float64))))
+
+
+def thermal_slab(b, omega, planck_layers, planck_sfc, cells_per_layer=150):
+    """An emitting, isotropically scattering slab over a black surface: `planck_layers` from the TOP layer down (equal
+    optical depth each), tau from the top.  S = (1 - omega) B + omega J, J = 1/2 int S E1 + 1/2 B_s E2(b - tau).
+    Returns (the layer's share of the emitted power, flux through the top, flux onto the surface) -- the fluxes as shares
+    of the emitted power 4 pi (1 - omega) int B dtau + pi B_s, which is how the integrator reports them."""
+    planck_layers = np.asarray(planck_layers, np.float64)
+    cells = cells_per_layer * len(planck_layers)
+    h = b / cells
+    edges = np.arange(cells + 1) * h
+    tc = edges[:-1] + 0.5 * h
+    kern = 0.5 * np.abs(expn(2, np.abs(tc[:, None] - edges[None, :-1])) - expn(2, np.abs(tc[:, None] - edges[None, 1:])))
+    kern[np.arange(cells), np.arange(cells)] = 1.0 - expn(2, 0.5 * h)
+    bb = np.repeat(planck_layers, cells_per_layer)
+    from_surface = 0.5 * planck_sfc * (expn(3, b - edges[1:]) - expn(3, b - edges[:-1])) / h   # cell mean of 1/2 B_s E2(b - t)
+    src = np.linalg.solve(np.eye(cells) - omega * kern, (1.0 - omega) * bb + omega * from_surface)
+    atm = 4.0 * np.pi * (1.0 - omega) * float(np.sum(bb)) * h
+    total = atm + np.pi * planck_sfc
+    up = (2.0 * np.pi * float(np.sum(src * (expn(3, edges[:-1]) - expn(3, edges[1:])))) + 2.0 * np.pi * planck_sfc * float(expn(3, b))) / total
+    down = 2.0 * np.pi * float(np.sum(src * (expn(3, b - edges[1:]) - expn(3, b - edges[:-1])))) / total
+    return atm / total, up, down
+
+
+def thermal_case(tau, ssa, temps_bottom_up, sfc_temp, lam=10.0):
+    n = len(temps_bottom_up)
+    case = cases.homog_lw(n=n, ext=tau / (0.1 * n), ssa=ssa, g=0.0, nleg=2, temp=280.0, sfc_temp=sfc_temp, albedo=0.0, lam=lam)
+    case["temps"] = np.broadcast_to(np.asarray(temps_bottom_up, np.float64)[None, None, :], case["temps"].shape).copy()
+    frac, up, down = thermal_slab(tau, ssa, planck(lam, np.asarray(temps_bottom_up)[::-1]), float(planck(lam, sfc_temp)))
+    return case, frac, up, down
+
+
+# (optical depth, omega0, layer temperatures from the surface up, surface temperature)
+THERMAL_SLABS = [(1.0, 0.5, [285.0] * 6, 285.0), (2.0, 0.8, [300.0, 294.0, 287.0, 279.0, 270.0, 260.0], 305.0),
+                 (0.5, 0.0, [250.0, 260.0, 270.0, 280.0, 290.0, 300.0], 240.0)]
+
 SCATTERING_SLABS = [(1.0, 1.0, 1.0), (2.0, 0.9, 0.5), (0.5, 1.0, 0.3), (4.0, 0.6, 0.8)]
 
 
@@ -161,6 +202,13 @@ def test_the_integral_equation_solver_conserves_energy_and_has_converged():
         up, down, direct = isotropic_slab(b, 1.0, mu0)
         assert abs(up + down + direct - 1.0) < 3e-6
         assert np.allclose(isotropic_slab(b, 1.0, mu0, cells=600)[:2], (up, down), atol=5e-6)
+
+
+def test_the_thermal_solver_has_the_closed_form_as_its_limit():
+    for tau in (0.25, 1.0, 3.0):
+        frac, up, down = thermal_slab(tau, 0.0, [1.0] * 4, 1.0)
+        e = 1.0 / (1.0 + 4.0 * tau)
+        assert abs(frac - 4.0 * tau * e) < 1e-9 and abs(up - e) < 2e-6 and abs(down - e * (1.0 - 2.0 * float(expn(3, tau)))) < 2e-6
 
 
 def test_the_two_deterministic_solvers_agree_on_isotropic_scattering():
@@ -261,6 +309,21 @@ def test_oracle_isothermal_layer_over_a_black_surface(tau):
     assert prof[-1] < 0.0 and abs(prof[0]) < abs(prof[-1])
 
 
+@pytest.mark.parametrize("tau,omega,temps,sfc", THERMAL_SLABS)
+def test_oracle_thermal_emission_with_scattering_against_the_integral_equation(tau, omega, temps, sfc):
+    """emission_weightingNEW + newPhotonStream_BBEmission + the LW tallies, with scattering and a temperature profile."""
+    from oracle import oracle as O
+    n = 200000
+    case, frac, up, down = thermal_case(tau, omega, temps, sfc)
+    P = cases.oracle_problem(case, nsteps=101, lw_flag=1.0)
+    vw, f, _ = O.emission_weighting(P, case["temps"].transpose(2, 1, 0).reshape(-1), case["lambda_um"], case["sfc_temp"])
+    assert abs(f - frac) < 2e-5   # (the reference's physical constants against the tests': a few 10^-6)
+    r = O.compute_radiative_transfer(P, O.EmissionSource(vw, f), O.philox_rng(SEED, 0), n)
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - down) < 6.0 * _sigma(down, n)
+    assert abs(r["meanFluxAbsorbed"] - (1.0 - up - down - frac)) < 6.0 * (_sigma(up, n) + _sigma(down, n))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the product, through the C ABI
 # ---------------------------------------------------------------------------------------------------------------------
@@ -356,3 +419,28 @@ def test_product_isothermal_layer_over_a_black_surface(tau):
     assert abs(r["meanFluxUp"] - e) < 4.5 * _sigma(e, n)
     assert abs(r["meanFluxDown"] - d) < 4.5 * _sigma(d, n)
     assert abs(r["meanFluxAbsorbed"] + d) < 4.5 * (_sigma(e, n) + _sigma(d, n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tau,omega,temps,sfc", THERMAL_SLABS)
+def test_product_thermal_emission_with_scattering_against_the_integral_equation(tau, omega, temps, sfc):
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    n = 4000000
+    case, frac, up, down = thermal_case(tau, omega, temps, sfc)
+    dom = cases.product_domain(case)
+    nx = len(case["xe"]) - 1
+    w = M.new_Weights(nx, nx, nx)
+    M.emission_weighting(dom, w, case["sfc_temp"])
+    assert abs(w.fracAtmsPower - frac) < 2e-5
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=101, useRayTracing=True, useRussianRoulette=True, LW_flag=1.0)
+    photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 12)
+    integ.resetMoments()
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n) == n
+    r = integ.reportResults()
+    assert integ.badPhotons() == 0
+    integ.finalize()
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - down) < 6.0 * _sigma(down, n)
+    assert abs(r["meanFluxAbsorbed"] - (1.0 - up - down - frac)) < 6.0 * (_sigma(up, n) + _sigma(down, n))
