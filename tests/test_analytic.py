@@ -25,6 +25,7 @@ C ABI, so that the two are also held to something neither of them wrote.
    the series it is given (`sampled_moments`; a property of the reference that the drop-in keeps, measured below).
 6. Thermal emission WITH scattering and a temperature profile: the integral equation again, with the source
    (1 - omega) B(tau) + omega J and the black surface's 1/2 B_s E2: power split, top and surface fluxes.
+7. Radiance: the formal solution I(mu) = 1/mu int S e^(-t/mu) dt with the isotropic slab's source function.
 """
 import numpy as np
 import pytest
@@ -194,6 +195,22 @@ def thermal_case(tau, ssa, temps_bottom_up, sfc_temp, lam=10.0):
 THERMAL_SLABS = [(1.0, 0.5, [285.0] * 6, 285.0), (2.0, 0.8, [300.0, 294.0, 287.0, 279.0, 270.0, 260.0], 305.0),
                  (0.5, 0.0, [250.0, 260.0, 270.0, 280.0, 290.0, 300.0], 240.0)]
 
+def isotropic_radiance(b, omega, mu0, mus, cells=1500):
+    """Radiance leaving the top of the isotropically scattering slab of `isotropic_slab` along the cosines `mus`, per unit
+    incident flux: I(mu) = 1/mu int S(t) e^(-t/mu) dt with the same source function (no azimuth: the scattering forgets it)."""
+    h = b / cells
+    edges = np.arange(cells + 1) * h
+    tc = edges[:-1] + 0.5 * h
+    kern = 0.5 * np.abs(expn(2, np.abs(tc[:, None] - edges[None, :-1])) - expn(2, np.abs(tc[:, None] - edges[None, 1:])))
+    kern[np.arange(cells), np.arange(cells)] = 1.0 - expn(2, 0.5 * h)
+    direct = (np.exp(-edges[:-1] / mu0) - np.exp(-edges[1:] / mu0)) / (4.0 * np.pi * h)
+    src = np.linalg.solve(np.eye(cells) - omega * kern, omega * direct)
+    return np.array([float(np.sum(src * (np.exp(-edges[:-1] / m) - np.exp(-edges[1:] / m)))) for m in mus])
+
+
+RADIANCE_SLABS = [(1.0, 1.0, 0.6), (3.0, 0.9, 1.0)]
+RADIANCE_MUS, RADIANCE_PHIS = [1.0, 0.7, 0.35], [0.0, 120.0, 250.0]
+
 SCATTERING_SLABS = [(1.0, 1.0, 1.0), (2.0, 0.9, 0.5), (0.5, 1.0, 0.3), (4.0, 0.6, 0.8)]
 
 
@@ -324,6 +341,25 @@ def test_oracle_thermal_emission_with_scattering_against_the_integral_equation(t
     assert abs(r["meanFluxAbsorbed"] - (1.0 - up - down - frac)) < 6.0 * (_sigma(up, n) + _sigma(down, n))
 
 
+@pytest.mark.parametrize("b,omega,mu0", RADIANCE_SLABS)
+@pytest.mark.parametrize("rr", [False, True])
+def test_oracle_radiance_of_an_isotropically_scattering_slab(b, omega, mu0, rr):
+    """computeIntensityContribution (:1623-1832: the local estimate at every scattering, its transmission along the view
+    ray, the normalisation) against the formal solution with the integral equation's source function -- with and without
+    the roulette on the estimates (unbiased by construction, Iwabuchi 2006)."""
+    from oracle import oracle as O
+    case = slab(b, omega, nz=16)
+    P = cases.oracle_problem(case, nsteps=9001)
+    I = cases.oracle_intensity(case, RADIANCE_MUS, RADIANCE_PHIS, n_angles=1801, use_russian_roulette=rr, zeta_min=0.3)
+    per, nb = 20000, 12
+    runs = np.array([O.compute_radiative_transfer_intensity(P, O.solar_source(mu0, 33.0), O.philox_rng(SEED, k * per), per, I)["meanIntensity"]
+                     for k in range(nb)], np.float64)
+    mean, err = runs.mean(axis=0), runs.std(axis=0, ddof=1) / np.sqrt(nb)
+    theory = isotropic_radiance(b, omega, mu0, RADIANCE_MUS)
+    assert np.all(err < 0.02 * theory)
+    assert np.all(np.abs(mean - theory) < 4.5 * err), (mean, theory, err)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the product, through the C ABI
 # ---------------------------------------------------------------------------------------------------------------------
@@ -444,3 +480,27 @@ def test_product_thermal_emission_with_scattering_against_the_integral_equation(
     assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
     assert abs(r["meanFluxDown"] - down) < 6.0 * _sigma(down, n)
     assert abs(r["meanFluxAbsorbed"] - (1.0 - up - down - frac)) < 6.0 * (_sigma(up, n) + _sigma(down, n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,omega,mu0", RADIANCE_SLABS)
+@pytest.mark.parametrize("rr", [False, True])
+def test_product_radiance_of_an_isotropically_scattering_slab(b, omega, mu0, rr):
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd import driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = slab(b, omega, nz=16)
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001, minForwardTableSize=1801, intensityMus=RADIANCE_MUS, intensityPhis=RADIANCE_PHIS,
+                            computeIntensity=True, useRussianRouletteForIntensity=rr)
+    photons = M.new_PhotonStream(mu0, 33.0, numberOfPhotons=10 ** 12)
+    integ.resetMoments()
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, 100000, 40) == 4000000
+    st = driver.statistics(driver.unpack_moments(integ.moments(), dom.numX, dom.numY, dom.numZ, len(RADIANCE_MUS)))
+    assert integ.badPhotons() == 0
+    integ.finalize()
+    mean, err = st["intensity"][0, 0, :], st["intensity_StdErr"][0, 0, :]
+    theory = isotropic_radiance(b, omega, mu0, RADIANCE_MUS)
+    assert np.all(err < 0.004 * theory)
+    assert np.all(np.abs(mean - theory) < 4.5 * err), (mean, theory, err)
