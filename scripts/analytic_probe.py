@@ -4,8 +4,8 @@ comparison at 4x10^6): isotropic slabs vs the integral equation, Henyey-Greenste
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import cases
-from tests.test_analytic import (isotropic_slab, doubling_slab, sampled_moments, slab, hg_slab, SCATTERING_SLABS, HG_SLABS,
-                                 HG_STREAMS, SEED)
+from tests.test_analytic import (isotropic_slab, doubling_slab, sampled_moments, slab, hg_slab, tabulated_slab, SCATTERING_SLABS,
+                                 HG_SLABS, HG_STREAMS, SEED)
 import mcbrat3d_amd as M
 from mcbrat3d_amd import driver
 from mcbrat3d_amd.integrator import new_RandomNumberSequence
@@ -33,3 +33,6 @@ for b, omega, g, nleg, node in HG_SLABS:
     case, chi = hg_slab(b, omega, g, nleg)
     mu0, up, down = doubling_slab(b, omega, sampled_moments(chi, table=9001), node, streams=HG_STREAMS)
     run(case, mu0, 20.0, "HG g %.2f (%d terms) b %.1f omega %.2f mu0 %.4f" % (g, nleg, b, omega, mu0), up, down)
+case, nodes = tabulated_slab(2.0, 0.9)
+mu0, up, down = doubling_slab(2.0, 0.9, sampled_moments(None, table=9001, nodes=nodes), 64, streams=HG_STREAMS)
+run(case, mu0, 20.0, "angle / value table (two lobes, 361 angles) b 2.0 omega 0.90 mu0 %.4f" % mu0, up, down)

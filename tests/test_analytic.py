@@ -94,7 +94,7 @@ def doubling_slab(b, omega, chi, node, streams=33, halvings=24):
     return float(mu[node]), float(2.0 * np.pi * np.sum(mu * c * (r @ inc))), float(2.0 * np.pi * np.sum(mu * c * (t @ inc)))
 
 
-def sampled_moments(chi, terms=256, table=None, q=24):
+def sampled_moments(chi, terms=256, table=None, q=24, nodes=None):
     """Legendre moments (chi_0 .. chi_{terms-1}) of the phase function the reference actually samples when it is handed a
     Legendre series.  Two of its rules matter, and the drop-in keeps both (its tables are the rules' bit for bit):
 
@@ -108,12 +108,17 @@ def sampled_moments(chi, terms=256, table=None, q=24):
       (it is 1 / nSteps of one at most): the angle is, to a part in nSteps, the table entry at the interval's start -- the
       LARGER angle of the two.  A staircase that moves the mean cosine by -1 / nSteps and adds 0.27 % to the backscatter of
       the same phase function at nSteps = 9001.  `table=nSteps`: the moments of that staircase over the polygon's table.
-    """
+
+    `nodes=(mu ascending, values)`: an angle / value ("Mie table") phase function, whose native angles the reference takes
+    as the polygon's nodes."""
     from numpy.polynomial.legendre import leggauss, legval, Legendre
-    chi = np.asarray(chi, np.float64)
-    n = max(len(chi) - 1, 2)
-    mus = np.concatenate([[-1.0], np.sort(Legendre.basis(n - 1).deriv().roots().real), [1.0]])  # computeLobattoTerms
-    vals = legval(mus, (2 * np.arange(len(chi)) + 1) * chi)
+    if nodes is not None:  # an angle / value phase function: its own angles are the polygon's nodes (:80-88)
+        mus, vals = np.asarray(nodes[0], np.float64), np.asarray(nodes[1], np.float64)
+    else:
+        chi = np.asarray(chi, np.float64)
+        n = max(len(chi) - 1, 2)
+        mus = np.concatenate([[-1.0], np.sort(Legendre.basis(n - 1).deriv().roots().real), [1.0]])  # computeLobattoTerms
+        vals = legval(mus, (2 * np.arange(len(chi)) + 1) * chi)
     if table is None:
         x, w = leggauss(q)
         half = 0.5 * (mus[1:] - mus[:-1])[:, None]
@@ -268,6 +273,27 @@ def test_the_reference_samples_its_lobatto_polygon_not_the_series():
     assert abs(r["meanFluxUp"] - up_polygon) < 4.0 * _sigma(up_polygon, n)
     assert abs(r["meanFluxUp"] - up_series) > 5.0 * _sigma(up_series, n)
     assert 0.012 < (up_series - up_polygon) / up_series < 0.022
+
+
+def tabulated_slab(tau, ssa, nz=16):
+    ang, val = cases.tabulated_two_lobe(361)
+    case = slab(tau, ssa, nz=nz)
+    comp = case["components"][0]
+    del comp["legendre"]
+    comp["tabulated"] = [(ang, val)]
+    return case, (np.cos(ang.astype(np.float64))[::-1], val.astype(np.float64)[::-1])
+
+
+def test_oracle_angle_value_phase_function_against_matrix_doubling():
+    """The "Mie table" storage (src/scatteringPhaseFunctions.f95:104-164; inverse table from the native angles,
+    inversePhaseFunctions.f95:80-88): a forward lobe plus a weak backward one on 361 angles."""
+    from oracle import oracle as O
+    n = 200000
+    case, nodes = tabulated_slab(2.0, 0.9)
+    mu0, up, down = doubling_slab(2.0, 0.9, sampled_moments(None, table=9001, nodes=nodes), 64, streams=HG_STREAMS)
+    r = O.compute_radiative_transfer(cases.oracle_problem(case, nsteps=9001), O.solar_source(mu0, 20.0), O.philox_rng(SEED, 0), n)
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - down) < 6.0 * _sigma(down, n)
 
 
 @pytest.mark.parametrize("b,omega,mu0", SCATTERING_SLABS)
@@ -504,3 +530,13 @@ def test_product_radiance_of_an_isotropically_scattering_slab(b, omega, mu0, rr)
     theory = isotropic_radiance(b, omega, mu0, RADIANCE_MUS)
     assert np.all(err < 0.004 * theory)
     assert np.all(np.abs(mean - theory) < 4.5 * err), (mean, theory, err)
+
+
+@pytest.mark.gpu
+def test_product_angle_value_phase_function_against_matrix_doubling():
+    n = 4000000
+    case, nodes = tabulated_slab(2.0, 0.9)
+    mu0, up, down = doubling_slab(2.0, 0.9, sampled_moments(None, table=9001, nodes=nodes), 64, streams=HG_STREAMS)
+    r = _solar(case, mu0, 20.0, n, table=9001)
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - down) < 6.0 * _sigma(down, n)
