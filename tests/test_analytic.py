@@ -25,6 +25,9 @@ C ABI, so that the two are also held to something neither of them wrote.
    the series it is given (`sampled_moments`; a property of the reference that the drop-in keeps, measured below).
 6. Thermal emission WITH scattering and a temperature profile: the integral equation again, with the source
    (1 - omega) B(tau) + omega J and the black surface's 1/2 B_s E2: power split, top and surface fluxes.
+8. Structure: eight unlike layers on irregular levels, two components per cell (a scatterer and an absorber, so that the
+   component pick decides every collision) and a Lambertian surface, against the layered integral equation with the
+   surface's return as one more unknown.
 7. Radiance: the formal solution I(mu) = 1/mu int S e^(-t/mu) dt with the isotropic slab's source function.
 """
 import numpy as np
@@ -213,6 +216,37 @@ def isotropic_radiance(b, omega, mu0, mus, cells=1500):
     return np.array([float(np.sum(src * (np.exp(-edges[:-1] / m) - np.exp(-edges[1:] / m)))) for m in mus])
 
 
+def layered_isotropic_slab(dtaus, omegas, mu0, albedo=0.0, cells_per_layer=150):
+    """The isotropically scattering slab again, now in layers (`dtaus`, `omegas` from the TOP layer down) over a Lambertian
+    surface of reflectance `albedo`: (flux through the top, flux onto the surface -- every arrival, as the integrator
+    counts them).  The surface is one more unknown: the flux F onto it returns albedo * F isotropically, i.e. the mean
+    intensity albedo * F / pi * 1/2 E2(b - tau) in the layer."""
+    dtaus, omegas = np.asarray(dtaus, np.float64), np.asarray(omegas, np.float64)
+    h = np.repeat(dtaus / cells_per_layer, cells_per_layer)
+    om = np.repeat(omegas, cells_per_layer)
+    edges = np.concatenate([[0.0], np.cumsum(h)])
+    b = edges[-1]
+    tc = 0.5 * (edges[:-1] + edges[1:])
+    cells = len(h)
+    kern = 0.5 * np.abs(expn(2, np.abs(tc[:, None] - edges[None, :-1])) - expn(2, np.abs(tc[:, None] - edges[None, 1:])))
+    kern[np.arange(cells), np.arange(cells)] = 1.0 - expn(2, 0.5 * h)
+    direct = (np.exp(-edges[:-1] / mu0) - np.exp(-edges[1:] / mu0)) / (4.0 * np.pi * h)
+    lamb = 0.5 * (expn(3, b - edges[1:]) - expn(3, b - edges[:-1])) / h / np.pi      # mean intensity per unit flux leaving the surface
+    to_top = 2.0 * np.pi * (expn(3, edges[:-1]) - expn(3, edges[1:]))                 # flux through the top per unit source in a cell
+    to_sfc = 2.0 * np.pi * (expn(3, b - edges[1:]) - expn(3, b - edges[:-1]))
+    # unknowns: the source in every cell and the flux F onto the surface
+    a = np.zeros((cells + 1, cells + 1))
+    a[:cells, :cells] = np.eye(cells) - om[:, None] * kern
+    a[:cells, cells] = -om * albedo * lamb
+    a[cells, :cells] = -to_sfc
+    a[cells, cells] = 1.0
+    rhs = np.concatenate([om * direct, [np.exp(-b / mu0)]])
+    sol = np.linalg.solve(a, rhs)
+    src, onto = sol[:cells], float(sol[cells])
+    up = float(np.sum(src * to_top)) + albedo * onto * 2.0 * float(expn(3, b))
+    return up, onto
+
+
 RADIANCE_SLABS = [(1.0, 1.0, 0.6), (3.0, 0.9, 1.0)]
 RADIANCE_MUS, RADIANCE_PHIS = [1.0, 0.7, 0.35], [0.0, 120.0, 250.0]
 
@@ -231,6 +265,45 @@ def test_the_thermal_solver_has_the_closed_form_as_its_limit():
         frac, up, down = thermal_slab(tau, 0.0, [1.0] * 4, 1.0)
         e = 1.0 / (1.0 + 4.0 * tau)
         assert abs(frac - 4.0 * tau * e) < 1e-9 and abs(up - e) < 2e-6 and abs(down - e * (1.0 - 2.0 * float(expn(3, tau)))) < 2e-6
+
+
+def test_the_layered_solver_reduces_to_the_homogeneous_one_and_conserves_energy():
+    up, down, direct = isotropic_slab(2.0, 0.9, 0.5)
+    u2, onto = layered_isotropic_slab([0.5, 1.0, 0.5], [0.9, 0.9, 0.9], 0.5, cells_per_layer=400)
+    assert abs(u2 - up) < 3e-6 and abs(onto - down - direct) < 3e-6
+    u3, onto3 = layered_isotropic_slab([0.3, 1.2, 0.5], [1.0, 1.0, 1.0], 0.7, albedo=0.6)
+    assert abs(u3 + (1.0 - 0.6) * onto3 - 1.0) < 3e-5 and onto3 > onto   # (450 cells: the midpoint rule is good to 10^-5 here)
+
+
+LAYERED = dict(dtaus=[0.05, 0.4, 1.5, 0.2, 0.9, 0.02, 0.6, 0.3], omegas=[1.0, 0.95, 0.999, 0.3, 0.8, 1.0, 0.9, 0.6])
+
+
+def layered_case(albedo):
+    """Eight layers of unlike thickness, extinction and single-scattering albedo (top down as in LAYERED) in TWO components:
+    a conservative scatterer and an absorber, mixed per layer -- so that the component pick (computeRT :759-760) decides
+    every collision -- both isotropic."""
+    dt, om = np.asarray(LAYERED["dtaus"]), np.asarray(LAYERED["omegas"])
+    nz = len(dt)
+    ze = np.concatenate([[0.0], np.cumsum(np.array([0.03, 0.05, 0.02, 0.08, 0.04, 0.06, 0.02, 0.05]))])
+    ext = (dt[::-1] / np.diff(ze))[None, None, :]      # per layer, bottom up
+    omb = om[::-1][None, None, :]
+    iso = [np.zeros(2, np.float32)]
+    comps = [dict(ext=ext * omb, ssa=np.ones_like(ext), pfIndex=np.ones(ext.shape, np.int32), legendre=iso),
+             dict(ext=ext * (1.0 - omb), ssa=np.zeros_like(ext), pfIndex=np.ones(ext.shape, np.int32), legendre=iso)]
+    return dict(name="layered", xe=np.array([0.0, 0.4]), ye=np.array([0.0, 0.7]), ze=ze, components=comps, albedo=albedo)
+
+
+@pytest.mark.parametrize("albedo,mu0", [(0.0, 0.8), (0.5, 0.35)])
+def test_oracle_layers_two_components_and_a_lambertian_surface(albedo, mu0):
+    """Vertical structure (irregular z levels: the bisection launch and the edge-table walk), two components per cell, and
+    the Lambertian surface (computeRT :640-700) against the layered integral equation."""
+    from oracle import oracle as O
+    n = 200000
+    up, onto = layered_isotropic_slab(LAYERED["dtaus"], LAYERED["omegas"], mu0, albedo=albedo)
+    r = O.compute_radiative_transfer(cases.oracle_problem(layered_case(albedo), nsteps=101), O.solar_source(mu0, 10.0), O.philox_rng(SEED, 0), n)
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - onto) < 6.0 * _sigma(min(onto, 0.5), n) * (1.0 + albedo)
+    assert abs(r["meanFluxAbsorbed"] - (1.0 - up - (1.0 - albedo) * onto)) < 6.0 * (_sigma(up, n) + _sigma(min(onto, 0.5), n))
 
 
 def test_the_two_deterministic_solvers_agree_on_isotropic_scattering():
@@ -540,3 +613,14 @@ def test_product_angle_value_phase_function_against_matrix_doubling():
     r = _solar(case, mu0, 20.0, n, table=9001)
     assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
     assert abs(r["meanFluxDown"] - down) < 6.0 * _sigma(down, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("albedo,mu0", [(0.0, 0.8), (0.5, 0.35)])
+def test_product_layers_two_components_and_a_lambertian_surface(albedo, mu0):
+    n = 4000000
+    up, onto = layered_isotropic_slab(LAYERED["dtaus"], LAYERED["omegas"], mu0, albedo=albedo)
+    r = _solar(layered_case(albedo), mu0, 10.0, n)
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - onto) < 6.0 * _sigma(min(onto, 0.5), n) * (1.0 + albedo)
+    assert abs(r["meanFluxAbsorbed"] - (1.0 - up - (1.0 - albedo) * onto)) < 6.0 * (_sigma(up, n) + _sigma(min(onto, 0.5), n))
