@@ -28,6 +28,8 @@ C ABI, so that the two are also held to something neither of them wrote.
 8. Structure: eight unlike layers on irregular levels, two components per cell (a scatterer and an absorber, so that the
    component pick decides every collision) and a Lambertian surface, against the layered integral equation with the
    surface's return as one more unknown.
+9. Geometry: a homogeneous medium on a stretched 3-D grid under a low sun must be the slab again (every face crossing and
+   periodic wrap adding up to nothing), in every column alike; columns 10^4 km wide must each be their own slab.
 7. Radiance: the formal solution I(mu) = 1/mu int S e^(-t/mu) dt with the isotropic slab's source function.
 """
 import numpy as np
@@ -304,6 +306,55 @@ def test_oracle_layers_two_components_and_a_lambertian_surface(albedo, mu0):
     assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
     assert abs(r["meanFluxDown"] - onto) < 6.0 * _sigma(min(onto, 0.5), n) * (1.0 + albedo)
     assert abs(r["meanFluxAbsorbed"] - (1.0 - up - (1.0 - albedo) * onto)) < 6.0 * (_sigma(up, n) + _sigma(min(onto, 0.5), n))
+
+
+def homogeneous_3d(tau, ssa, g, nleg):
+    """One medium in 7 x 5 x 12 cells of unlike size (stretched in x, y and z): whatever the grid, the answer is the slab's."""
+    xe = np.concatenate([[0.0], np.cumsum(0.02 * 1.35 ** np.arange(7))])
+    ye = np.concatenate([[0.0], np.cumsum(0.05 * 0.8 ** np.arange(5))])
+    ze = np.concatenate([[0.0], np.cumsum(0.01 * 1.2 ** np.arange(12))])
+    ext = np.full((7, 5, 12), tau / ze[-1])
+    leg = [cases.hg_legendre(g, nleg)] if g else [np.zeros(2, np.float32)]
+    return dict(name="homogeneous3d", xe=xe, ye=ye, ze=ze, albedo=0.0,
+                components=[dict(ext=ext, ssa=np.full_like(ext, ssa), pfIndex=np.ones(ext.shape, np.int32), legendre=leg)])
+
+
+def wide_columns(taus, ssa, width_km=1.0e4):
+    """Columns so wide that none knows of its neighbours: each is its own slab (the independent-column limit)."""
+    nx, nz = len(taus), 8
+    xe = width_km * np.arange(nx + 1)
+    ze = 0.03125 * np.arange(nz + 1)
+    ext = np.repeat((np.asarray(taus, np.float64) / ze[-1])[:, None, None], nz, axis=2)
+    return dict(name="wideColumns", xe=xe, ye=np.array([0.0, width_km]), ze=ze, albedo=0.0,
+                components=[dict(ext=ext, ssa=np.full_like(ext, ssa), pfIndex=np.ones(ext.shape, np.int32),
+                                 legendre=[np.zeros(2, np.float32)])])
+
+
+def test_oracle_a_homogeneous_medium_on_a_stretched_3d_grid_is_the_slab():
+    """Every x / y / z face crossing, the periodic wraps (a sun at 20 degrees elevation carries a photon through the domain's
+    sides many times) and the irregular-grid launch must add up to nothing: accumulateExtinctionAlongPath
+    (src/opticalProperties.f95:1696-1812) against the integral equation."""
+    from oracle import oracle as O
+    n = 200000
+    up, down, direct = isotropic_slab(1.5, 0.95, 0.35)
+    r = O.compute_radiative_transfer(cases.oracle_problem(homogeneous_3d(1.5, 0.95, 0.0, 0), nsteps=101), O.solar_source(0.35, 57.0),
+                                     O.philox_rng(SEED, 0), n)
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - down - direct) < 6.0 * _sigma(down + direct, n)
+    # ... and in every column alike (the normalisation by column area, reportResults :877-884)
+    col = np.asarray(r["fluxUp"], np.float64)
+    assert col.size == 35 and np.all(np.abs(col - up) < 6.0 * _sigma(up, n / 35.0) * 3.0)
+
+
+def test_oracle_wide_columns_are_independent_slabs():
+    from oracle import oracle as O
+    n = 300000
+    taus = [2.0, 18.0, 0.5]
+    r = O.compute_radiative_transfer(cases.oracle_problem(wide_columns(taus, 0.99), nsteps=101), O.solar_source(0.7, 0.0), O.philox_rng(SEED, 0), n)
+    for i, tau in enumerate(taus):
+        up, down, direct = isotropic_slab(tau, 0.99, 0.7)
+        assert abs(float(r["fluxUp"][i]) - up) < 6.0 * _sigma(up, n / 3.0)
+        assert abs(float(r["fluxDown"][i]) - down - direct) < 6.0 * _sigma(down + direct, n / 3.0)
 
 
 def test_the_two_deterministic_solvers_agree_on_isotropic_scattering():
@@ -624,3 +675,41 @@ def test_product_layers_two_components_and_a_lambertian_surface(albedo, mu0):
     assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
     assert abs(r["meanFluxDown"] - onto) < 6.0 * _sigma(min(onto, 0.5), n) * (1.0 + albedo)
     assert abs(r["meanFluxAbsorbed"] - (1.0 - up - (1.0 - albedo) * onto)) < 6.0 * (_sigma(up, n) + _sigma(min(onto, 0.5), n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("walk", ["default", "face by face", "layers", "global tallies"])
+def test_product_a_homogeneous_medium_on_a_stretched_3d_grid_is_the_slab(walk):
+    """... through every walk the product has for such a grid (the default plan folds a homogeneous medium into one block)."""
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    n = 4000000
+    case, chi = homogeneous_3d(3.0, 0.9, 0.6, 48), np.concatenate([[1.0], cases.hg_legendre(0.6, 48).astype(np.float64)])
+    mu0, up, down = doubling_slab(3.0, 0.9, sampled_moments(chi, table=9001), 40, streams=HG_STREAMS)
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True)
+    tuning = {"default": {}, "face by face": dict(blockWalk=0, layerSkip=0), "layers": dict(blockWalk=0, layerSkip=1),
+              "global tallies": dict(blockWalk=0, layerSkip=1, privateTallies=0)}[walk]
+    if tuning:
+        integ.setTuning(**tuning)
+    photons = M.new_PhotonStream(mu0, 57.0, numberOfPhotons=10 ** 12)
+    integ.resetMoments()
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n) == n
+    r = integ.reportResults()
+    assert integ.badPhotons() == 0
+    integ.finalize()
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - down) < 6.0 * _sigma(down, n)
+    assert np.all(np.abs(np.asarray(r["fluxUp"], np.float64) - up) < 6.0 * _sigma(up, n / 35.0) * 3.0)
+
+
+@pytest.mark.gpu
+def test_product_wide_columns_are_independent_slabs():
+    n = 6000000
+    taus = [2.0, 18.0, 0.5]
+    r = _solar(wide_columns(taus, 0.99), 0.7, 0.0, n)
+    for i, tau in enumerate(taus):
+        up, down, direct = isotropic_slab(tau, 0.99, 0.7)
+        assert abs(float(r["fluxUp"][i, 0]) - up) < 6.0 * _sigma(up, n / 3.0)
+        assert abs(float(r["fluxDown"][i, 0]) - down - direct) < 6.0 * _sigma(down + direct, n / 3.0)
