@@ -30,6 +30,8 @@ C ABI, so that the two are also held to something neither of them wrote.
    surface's return as one more unknown.
 9. Geometry: a homogeneous medium on a stretched 3-D grid under a low sun must be the slab again (every face crossing and
    periodic wrap adding up to nothing), in every column alike; columns 10^4 km wide must each be their own slab.
+10. Config 4's kind of problem: an isothermal layer with forward scattering over a warmer grey surface, against matrix
+   doubling with Kirchhoff's emission B (1 - r 1 - t 1) and the surface's emission and reflection as one unknown.
 7. Radiance: the formal solution I(mu) = 1/mu int S e^(-t/mu) dt with the isotropic slab's source function.
 """
 import numpy as np
@@ -71,12 +73,12 @@ def isotropic_slab(b, omega, mu0, cells=1500):
     return up, down, float(np.exp(-b / mu0))
 
 
-def doubling_slab(b, omega, chi, node, streams=33, halvings=24):
-    """(mu0, reflected, transmitted incl. direct) for a slab with the phase function sum_l (2 l + 1) chi_l P_l (chi_0 = 1),
-    the sun along Gauss node `node` of `streams` nodes on (0, 1) (an odd count holds mu0 = 0.5 exactly), black surface.
-    Matrix doubling from a layer of b / 2^halvings: r = dt M^-1 (omega/2) P+- C, t = E - dt M^-1 (E - (omega/2) P++ C);
-    two equal layers: R = r + t (E - r r)^-1 r t, T = t (E - r r)^-1 t.  (`streams` Gauss nodes carry 2 streams - 1 terms.)  Independent of `isotropic_slab`, and equal to it to
-    10^-6 on isotropic scattering (tested below); 33 streams carry 65 Legendre terms to 7 digits."""
+def doubling_matrices(b, omega, chi, streams=33, halvings=24):
+    """(mu, c, r, t): Gauss nodes and weights on (0, 1) and the reflection / transmission operators of a homogeneous slab
+    (optical depth b, albedo omega, phase function sum_l (2 l + 1) chi_l P_l with chi_0 = 1) on azimuthally averaged
+    intensities at the nodes.  Matrix doubling from a layer of b / 2^halvings: r = dt M^-1 (omega/2) P+- C,
+    t = E - dt M^-1 (E - (omega/2) P++ C); two equal layers: R = r + t (E - r r)^-1 r t, T = t (E - r r)^-1 t.
+    (`streams` Gauss nodes carry 2 streams - 1 Legendre terms.)"""
     from numpy.polynomial.legendre import leggauss, legval
     x, w = leggauss(streams)
     mu, c = 0.5 * (x + 1.0), 0.5 * w
@@ -94,9 +96,38 @@ def doubling_slab(b, omega, chi, node, streams=33, halvings=24):
     for _ in range(halvings):
         g = np.linalg.inv(e - r @ r)
         r, t = r + t @ g @ r @ t, t @ g @ t
+    return mu, c, r, t
+
+
+def doubling_slab(b, omega, chi, node, streams=33, halvings=24):
+    """(mu0, reflected, transmitted incl. direct) share of the incident flux for the sun along Gauss node `node` (an odd
+    count of streams holds mu0 = 0.5 exactly), black surface.  Independent of `isotropic_slab`, and equal to it to 10^-6 on
+    isotropic scattering (tested below); 33 streams carry 65 Legendre terms to 7 digits."""
+    mu, c, r, t = doubling_matrices(b, omega, chi, streams, halvings)
     inc = np.zeros(streams)
     inc[node] = 1.0 / (2.0 * np.pi * mu[node] * c[node])
     return float(mu[node]), float(2.0 * np.pi * np.sum(mu * c * (r @ inc))), float(2.0 * np.pi * np.sum(mu * c * (t @ inc)))
+
+
+def thermal_doubling(b, omega, chi, planck_layer, planck_sfc, albedo, streams=33):
+    """An isothermal, homogeneous, emitting and anisotropically scattering layer over a Lambertian surface of reflectance
+    `albedo` and emissivity 1 - albedo (emission_weightingNEW :478).  Kirchhoff gives the layer's own emission from its
+    reflection and transmission: in an enclosure at its temperature every outgoing intensity is B, so it emits
+    B (1 - r 1 - t 1) into each direction; the surface sends (1 - albedo) B_s + albedo F / pi upward, F the flux onto it.
+    Returns (the layer's share of the emitted power, flux through the top, flux onto the surface) as shares of the emitted
+    power 4 pi (1 - omega) B b + pi (1 - albedo) B_s."""
+    mu, c, r, t = doubling_matrices(b, omega, chi, streams)
+    one = np.ones(streams)
+    flux = lambda v: float(2.0 * np.pi * np.sum(mu * c * v))  # noqa: E731
+    emit = planck_layer * (one - r @ one - t @ one)
+    # F = flux(emit) + I_s flux(r 1),  I_s = (1 - albedo) B_s + albedo F / pi
+    f_r, f_t = flux(r @ one), flux(t @ one)
+    onto = (flux(emit) + (1.0 - albedo) * planck_sfc * f_r) / (1.0 - albedo * f_r / np.pi)
+    i_s = (1.0 - albedo) * planck_sfc + albedo * onto / np.pi
+    up = flux(emit) + i_s * f_t
+    atm = 4.0 * np.pi * (1.0 - omega) * planck_layer * b
+    total = atm + np.pi * (1.0 - albedo) * planck_sfc
+    return atm / total, up / total, onto / total
 
 
 def sampled_moments(chi, terms=256, table=None, q=24, nodes=None):
@@ -355,6 +386,39 @@ def test_oracle_wide_columns_are_independent_slabs():
         up, down, direct = isotropic_slab(tau, 0.99, 0.7)
         assert abs(float(r["fluxUp"][i]) - up) < 6.0 * _sigma(up, n / 3.0)
         assert abs(float(r["fluxDown"][i]) - down - direct) < 6.0 * _sigma(down + direct, n / 3.0)
+
+
+def test_the_thermal_doubling_agrees_with_the_thermal_integral_equation_on_isotropic_scattering():
+    for b, omega in ((1.0, 0.5), (3.0, 0.9)):
+        f1, u1, d1 = thermal_slab(b, omega, [0.8] * 4, 1.3)
+        f2, u2, d2 = thermal_doubling(b, omega, [1.0], 0.8, 1.3, 0.0)
+        assert abs(f1 - f2) < 1e-9 and abs(u1 - u2) < 5e-6 and abs(d1 - d2) < 5e-6
+
+
+def config4_like(tau, ssa, g, nleg, temp, sfc_temp, albedo, n=6, lam=10.0):
+    case = cases.homog_lw(n=n, ext=tau / (0.1 * n), ssa=ssa, g=g, nleg=nleg, temp=temp, sfc_temp=sfc_temp, albedo=albedo, lam=lam)
+    chi = np.concatenate([[1.0], np.asarray(case["components"][0]["legendre"][0], np.float64)])
+    theory = thermal_doubling(tau, ssa, sampled_moments(chi, table=9001), float(planck(lam, temp)), float(planck(lam, sfc_temp)), albedo,
+                              streams=HG_STREAMS)
+    return case, theory
+
+
+# config 4's kind of problem (Domain-Files/homogBBDomain.f95:39-66: homogeneous, isothermal 280 K over a warmer surface of
+# albedo 0.1, optical depth 10, omega0 = 0.5), with a phase function whose Legendre series has converged
+CONFIG4_LIKE = [(10.0, 0.5, 0.6, 48, 280.0, 300.0, 0.1), (2.0, 0.9, 0.85, 64, 250.0, 290.0, 0.4)]
+
+
+@pytest.mark.parametrize("tau,ssa,g,nleg,temp,sfc,albedo", CONFIG4_LIKE)
+def test_oracle_thermal_emission_forward_scattering_and_a_grey_surface(tau, ssa, g, nleg, temp, sfc, albedo):
+    from oracle import oracle as O
+    n = 300000
+    case, (frac, up, onto) = config4_like(tau, ssa, g, nleg, temp, sfc, albedo)
+    P = cases.oracle_problem(case, nsteps=9001, lw_flag=1.0)
+    vw, f, _ = O.emission_weighting(P, case["temps"].transpose(2, 1, 0).reshape(-1), case["lambda_um"], case["sfc_temp"])
+    assert abs(f - frac) < 2e-5
+    r = O.compute_radiative_transfer(P, O.EmissionSource(vw, f), O.philox_rng(SEED, 0), n)
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - onto) < 6.0 * _sigma(min(onto, 0.5), n) * (1.0 + albedo)
 
 
 def test_the_two_deterministic_solvers_agree_on_isotropic_scattering():
@@ -713,3 +777,27 @@ def test_product_wide_columns_are_independent_slabs():
         up, down, direct = isotropic_slab(tau, 0.99, 0.7)
         assert abs(float(r["fluxUp"][i, 0]) - up) < 6.0 * _sigma(up, n / 3.0)
         assert abs(float(r["fluxDown"][i, 0]) - down - direct) < 6.0 * _sigma(down + direct, n / 3.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tau,ssa,g,nleg,temp,sfc,albedo", CONFIG4_LIKE)
+def test_product_thermal_emission_forward_scattering_and_a_grey_surface(tau, ssa, g, nleg, temp, sfc, albedo):
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    n = 6000000
+    case, (frac, up, onto) = config4_like(tau, ssa, g, nleg, temp, sfc, albedo)
+    dom = cases.product_domain(case)
+    nx = len(case["xe"]) - 1
+    w = M.new_Weights(nx, nx, nx)
+    M.emission_weighting(dom, w, case["sfc_temp"])
+    assert abs(w.fracAtmsPower - frac) < 2e-5
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True, LW_flag=1.0)
+    photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 12)
+    integ.resetMoments()
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, n) == n
+    r = integ.reportResults()
+    assert integ.badPhotons() == 0
+    integ.finalize()
+    assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
+    assert abs(r["meanFluxDown"] - onto) < 6.0 * _sigma(min(onto, 0.5), n) * (1.0 + albedo)
