@@ -32,7 +32,8 @@ C ABI, so that the two are also held to something neither of them wrote.
    periodic wrap adding up to nothing), in every column alike; columns 10^4 km wide must each be their own slab.
 10. Config 4's kind of problem: an isothermal layer with forward scattering over a warmer grey surface, against matrix
    doubling with Kirchhoff's emission B (1 - r 1 - t 1) and the surface's emission and reflection as one unknown.
-7. Radiance: the formal solution I(mu) = 1/mu int S e^(-t/mu) dt with the isotropic slab's source function.
+7. Radiance: the formal solution I(mu) = 1/mu int S e^(-t/mu) dt with the isotropic slab's source function; and, for a
+   forward-scattering slab, the mean over 12 view azimuths against the reflection operator of the doubling solver.
 """
 import numpy as np
 import pytest
@@ -279,6 +280,18 @@ def layered_isotropic_slab(dtaus, omegas, mu0, albedo=0.0, cells_per_layer=150):
     up = float(np.sum(src * to_top)) + albedo * onto * 2.0 * float(expn(3, b))
     return up, onto
 
+
+def doubling_radiance(b, omega, chi, node, view_nodes, streams=129):
+    """Azimuthal mean of the radiance leaving the top along the Gauss nodes `view_nodes`, per unit incident flux, sun along
+    node `node`: row `view` of the reflection operator applied to the beam."""
+    mu, c, r, _ = doubling_matrices(b, omega, chi, streams)
+    inc = np.zeros(streams)
+    inc[node] = 1.0 / (2.0 * np.pi * mu[node] * c[node])
+    out = r @ inc
+    return float(mu[node]), [float(mu[v]) for v in view_nodes], np.array([float(out[v]) for v in view_nodes])
+
+
+RADIANCE_AZIMUTHS = 12   # (the mean over 12 equally spaced azimuths is the azimuthal mean up to the 12th Fourier mode: g^12 = 0.2 % at g = 0.6)
 
 RADIANCE_SLABS = [(1.0, 1.0, 0.6), (3.0, 0.9, 1.0)]
 RADIANCE_MUS, RADIANCE_PHIS = [1.0, 0.7, 0.35], [0.0, 120.0, 250.0]
@@ -574,6 +587,27 @@ def test_oracle_radiance_of_an_isotropically_scattering_slab(b, omega, mu0, rr):
     assert np.all(np.abs(mean - theory) < 4.5 * err), (mean, theory, err)
 
 
+def test_oracle_radiance_of_a_forward_scattering_slab_in_the_azimuthal_mean():
+    """The local estimate WITH its phase-function factor (the forward tables, tabulateForwardPhaseFunctions) against matrix
+    doubling: the mean over 12 view azimuths is the azimuthal mean that the reflection operator carries."""
+    from oracle import oracle as O
+    case, chi = hg_slab(2.0, 0.95, 0.6, 48)
+    # (theory for the SERIES: the estimate's own phase-function factor -- most of the radiance at these angles -- comes from the
+    # forward tables, which hold the series; the polygon the directions are sampled from differs from it by up to 1 % at
+    # single angles and by 10^-4 in this slab's fluxes, which is what the earlier scatterings contribute through)
+    mu0, vmus, theory = doubling_radiance(2.0, 0.95, chi, 64, [64, 110])
+    mus = [m for m in vmus for _ in range(RADIANCE_AZIMUTHS)]
+    phis = [360.0 * k / RADIANCE_AZIMUTHS for _ in vmus for k in range(RADIANCE_AZIMUTHS)]
+    P = cases.oracle_problem(case, nsteps=9001)
+    I = cases.oracle_intensity(case, mus, phis, n_angles=1801)
+    per, nb = 10000, 10
+    runs = np.array([O.compute_radiative_transfer_intensity(P, O.solar_source(mu0, 0.0), O.philox_rng(SEED, k * per), per, I)["meanIntensity"]
+                     for k in range(nb)], np.float64).reshape(nb, len(vmus), RADIANCE_AZIMUTHS).mean(axis=2)
+    mean, err = runs.mean(axis=0), runs.std(axis=0, ddof=1) / np.sqrt(nb)
+    assert np.all(err < 0.02 * theory)
+    assert np.all(np.abs(mean - theory) < 4.5 * err + 0.003 * theory), (mean, theory, err)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the product, through the C ABI
 # ---------------------------------------------------------------------------------------------------------------------
@@ -801,3 +835,34 @@ def test_product_thermal_emission_forward_scattering_and_a_grey_surface(tau, ssa
     integ.finalize()
     assert abs(r["meanFluxUp"] - up) < 6.0 * _sigma(up, n)
     assert abs(r["meanFluxDown"] - onto) < 6.0 * _sigma(min(onto, 0.5), n) * (1.0 + albedo)
+
+
+@pytest.mark.gpu
+def test_product_radiance_of_a_forward_scattering_slab_in_the_azimuthal_mean():
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd import driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case, chi = hg_slab(2.0, 0.95, 0.6, 48)
+    # (theory for the SERIES: the estimate's own phase-function factor -- most of the radiance at these angles -- comes from the
+    # forward tables, which hold the series; the polygon the directions are sampled from differs from it by up to 1 % at
+    # single angles and by 10^-4 in this slab's fluxes, which is what the earlier scatterings contribute through)
+    mu0, vmus, theory = doubling_radiance(2.0, 0.95, chi, 64, [64, 110])
+    mus = [m for m in vmus for _ in range(RADIANCE_AZIMUTHS)]
+    phis = [360.0 * k / RADIANCE_AZIMUTHS for _ in vmus for k in range(RADIANCE_AZIMUTHS)]
+    dom = cases.product_domain(case)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=9001, minForwardTableSize=1801, intensityMus=mus, intensityPhis=phis, computeIntensity=True)
+    photons = M.new_PhotonStream(mu0, 0.0, numberOfPhotons=10 ** 12)
+    integ.resetMoments()
+    nb = 40
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, 50000, nb) == 50000 * nb
+    st = driver.statistics(driver.unpack_moments(integ.moments(), dom.numX, dom.numY, dom.numZ, len(mus)))
+    assert integ.badPhotons() == 0
+    integ.finalize()
+    per_dir, err_dir = st["intensity"][0, 0, :].reshape(len(vmus), -1), st["intensity_StdErr"][0, 0, :].reshape(len(vmus), -1)
+    mean = per_dir.mean(axis=1)
+    err = np.sqrt((err_dir ** 2).sum(axis=1)) / RADIANCE_AZIMUTHS * 1.5   # (the directions share their photons: correlated, so with room)
+    assert np.all(err < 0.01 * theory)
+    assert np.all(np.abs(mean - theory) < 4.5 * err + 0.003 * theory), (mean, theory, err)
+    # ... and the field is not isotropic in azimuth (the test would pass trivially if it were)
+    assert per_dir[0].max() > 1.05 * per_dir[0].min()
