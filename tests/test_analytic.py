@@ -33,7 +33,8 @@ C ABI, so that the two are also held to something neither of them wrote.
 10. Config 4's kind of problem: an isothermal layer with forward scattering over a warmer grey surface, against matrix
    doubling with Kirchhoff's emission B (1 - r 1 - t 1) and the surface's emission and reflection as one unknown.
 7. Radiance: the formal solution I(mu) = 1/mu int S e^(-t/mu) dt with the isotropic slab's source function; and, for a
-   forward-scattering slab, the mean over 12 view azimuths against the reflection operator of the doubling solver.
+   forward-scattering slab, the mean over 12 view azimuths against the reflection operator of the doubling solver; thermal
+   radiance (emission seen directly + the scattered field) against the thermal integral equation's formal solution.
 """
 import numpy as np
 import pytest
@@ -223,6 +224,23 @@ def thermal_slab(b, omega, planck_layers, planck_sfc, cells_per_layer=150):
     up = (2.0 * np.pi * float(np.sum(src * (expn(3, edges[:-1]) - expn(3, edges[1:])))) + 2.0 * np.pi * planck_sfc * float(expn(3, b))) / total
     down = 2.0 * np.pi * float(np.sum(src * (expn(3, b - edges[1:]) - expn(3, b - edges[:-1])))) / total
     return atm / total, up, down
+
+
+def thermal_radiance(b, omega, planck_layers, planck_sfc, mus, cells_per_layer=150):
+    """Radiance leaving the top of `thermal_slab`'s layer along the cosines `mus`, as a share of the emitted power:
+    I(mu) = 1/mu int S e^(-t/mu) dt + B_s e^(-b/mu)."""
+    planck_layers = np.asarray(planck_layers, np.float64)
+    cells = cells_per_layer * len(planck_layers)
+    h = b / cells
+    edges = np.arange(cells + 1) * h
+    tc = edges[:-1] + 0.5 * h
+    kern = 0.5 * np.abs(expn(2, np.abs(tc[:, None] - edges[None, :-1])) - expn(2, np.abs(tc[:, None] - edges[None, 1:])))
+    kern[np.arange(cells), np.arange(cells)] = 1.0 - expn(2, 0.5 * h)
+    bb = np.repeat(planck_layers, cells_per_layer)
+    from_surface = 0.5 * planck_sfc * (expn(3, b - edges[1:]) - expn(3, b - edges[:-1])) / h
+    src = np.linalg.solve(np.eye(cells) - omega * kern, (1.0 - omega) * bb + omega * from_surface)
+    total = 4.0 * np.pi * (1.0 - omega) * float(np.sum(bb)) * h + np.pi * planck_sfc
+    return np.array([(float(np.sum(src * (np.exp(-edges[:-1] / m) - np.exp(-edges[1:] / m)))) + planck_sfc * np.exp(-b / m)) / total for m in mus])
 
 
 def thermal_case(tau, ssa, temps_bottom_up, sfc_temp, lam=10.0):
@@ -587,6 +605,25 @@ def test_oracle_radiance_of_an_isotropically_scattering_slab(b, omega, mu0, rr):
     assert np.all(np.abs(mean - theory) < 4.5 * err), (mean, theory, err)
 
 
+@pytest.mark.parametrize("tau,omega,temps,sfc", THERMAL_SLABS[:2])
+def test_oracle_thermal_radiance_against_the_formal_solution(tau, omega, temps, sfc):
+    """Emission seen directly (the local estimates at launch, computeRT :510-541), attenuated, plus the scattered field:
+    in the isothermal case without scattering the answer is B itself in every direction."""
+    from oracle import oracle as O
+    lam = 10.0
+    case, _, _, _ = thermal_case(tau, omega, temps, sfc, lam)
+    theory = thermal_radiance(tau, omega, planck(lam, np.asarray(temps)[::-1]), float(planck(lam, sfc)), RADIANCE_MUS)
+    P = cases.oracle_problem(case, nsteps=101, lw_flag=1.0)
+    vw, f, _ = O.emission_weighting(P, case["temps"].transpose(2, 1, 0).reshape(-1), lam, sfc)
+    I = cases.oracle_intensity(case, RADIANCE_MUS, RADIANCE_PHIS, n_angles=181)
+    per, nb = 20000, 10
+    runs = np.array([O.compute_radiative_transfer_intensity(P, O.EmissionSource(vw, f), O.philox_rng(SEED, k * per), per, I)["meanIntensity"]
+                     for k in range(nb)], np.float64)
+    mean, err = runs.mean(axis=0), runs.std(axis=0, ddof=1) / np.sqrt(nb)
+    assert np.all(err < 0.02 * theory)
+    assert np.all(np.abs(mean - theory) < 4.5 * err), (mean, theory, err)
+
+
 def test_oracle_radiance_of_a_forward_scattering_slab_in_the_azimuthal_mean():
     """The local estimate WITH its phase-function factor (the forward tables, tabulateForwardPhaseFunctions) against matrix
     doubling: the mean over 12 view azimuths is the azimuthal mean that the reflection operator carries."""
@@ -866,3 +903,33 @@ def test_product_radiance_of_a_forward_scattering_slab_in_the_azimuthal_mean():
     assert np.all(np.abs(mean - theory) < 4.5 * err + 0.003 * theory), (mean, theory, err)
     # ... and the field is not isotropic in azimuth (the test would pass trivially if it were)
     assert per_dir[0].max() > 1.05 * per_dir[0].min()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tau,omega,temps,sfc", THERMAL_SLABS[:2] + [(1.0, 0.0, [285.0] * 6, 285.0)])
+def test_product_thermal_radiance_against_the_formal_solution(tau, omega, temps, sfc):
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd import driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    lam = 10.0
+    case, _, _, _ = thermal_case(tau, omega, temps, sfc, lam)
+    theory = thermal_radiance(tau, omega, planck(lam, np.asarray(temps)[::-1]), float(planck(lam, sfc)), RADIANCE_MUS)
+    if omega == 0.0 and len(set(temps)) == 1 and temps[0] == sfc:  # Kirchhoff: B itself, as a share of pi B (1 + 4 tau)
+        assert np.allclose(theory, 1.0 / (np.pi * (1.0 + 4.0 * tau)), rtol=2e-6)
+    dom = cases.product_domain(case)
+    nx = len(case["xe"]) - 1
+    w = M.new_Weights(nx, nx, nx)
+    M.emission_weighting(dom, w, sfc)
+    integ = M.new_Integrator(dom)
+    integ.specifyParameters(minInverseTableSize=101, minForwardTableSize=181, LW_flag=1.0, intensityMus=RADIANCE_MUS, intensityPhis=RADIANCE_PHIS,
+                            computeIntensity=True)
+    photons = M.new_PhotonStream(theseWeights=w, numberOfPhotons=10 ** 12)
+    integ.resetMoments()
+    assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, 100000, 40) == 4000000
+    st = driver.statistics(driver.unpack_moments(integ.moments(), dom.numX, dom.numY, dom.numZ, len(RADIANCE_MUS)))
+    assert integ.badPhotons() == 0
+    integ.finalize()
+    mean = st["intensity"].reshape(-1, len(RADIANCE_MUS)).mean(axis=0)
+    err = np.sqrt((st["intensity_StdErr"].reshape(-1, len(RADIANCE_MUS)) ** 2).sum(axis=0)) / (nx * nx)
+    assert np.all(err < 0.005 * theory)
+    assert np.all(np.abs(mean - theory) < 4.5 * err), (mean, theory, err)
