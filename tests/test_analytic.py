@@ -1,7 +1,7 @@
 """Known answers that come from physics, not from the oracle: the closed forms a plane-parallel medium has.  The reference
-holds no tests (its authors validated "by eye against analytic / plane-parallel results"); these are
-the three such results that are exact, applied to the ORACLE on the CPU and -- marked gpu -- to the product through the
-C ABI, so that the two are also held to something neither of them wrote.
+holds no tests (its authors validated "by eye against analytic / plane-parallel results"); here are
+the closed forms that are exact and two deterministic solvers written for the purpose, applied to the ORACLE on the CPU
+and -- marked gpu -- to the product through the C ABI, so that the two are also held to something neither of them wrote.
 
 1. Beer-Lambert: omega0 = 0, sun at mu0: the surface receives exp(-tau / mu0), nothing leaves the top
    (accumulateExtinctionAlongPath, src/opticalProperties.f95:1696-1812, and nothing else).
@@ -25,6 +25,9 @@ C ABI, so that the two are also held to something neither of them wrote.
    the series it is given (`sampled_moments`; a property of the reference that the drop-in keeps, measured below).
 6. Thermal emission WITH scattering and a temperature profile: the integral equation again, with the source
    (1 - omega) B(tau) + omega J and the black surface's 1/2 B_s E2: power split, top and surface fluxes.
+7. Radiance: the formal solution I(mu) = 1/mu int S e^(-t/mu) dt with the isotropic slab's source function; and, for a
+   forward-scattering slab, the mean over 12 view azimuths against the reflection operator of the doubling solver; thermal
+   radiance (emission seen directly + the scattered field) against the thermal integral equation's formal solution.
 8. Structure: eight unlike layers on irregular levels, two components per cell (a scatterer and an absorber, so that the
    component pick decides every collision) and a Lambertian surface, against the layered integral equation with the
    surface's return as one more unknown.
@@ -32,9 +35,6 @@ C ABI, so that the two are also held to something neither of them wrote.
    periodic wrap adding up to nothing), in every column alike; columns 10^4 km wide must each be their own slab.
 10. Config 4's kind of problem: an isothermal layer with forward scattering over a warmer grey surface, against matrix
    doubling with Kirchhoff's emission B (1 - r 1 - t 1) and the surface's emission and reflection as one unknown.
-7. Radiance: the formal solution I(mu) = 1/mu int S e^(-t/mu) dt with the isotropic slab's source function; and, for a
-   forward-scattering slab, the mean over 12 view azimuths against the reflection operator of the doubling solver; thermal
-   radiance (emission seen directly + the scattered field) against the thermal integral equation's formal solution.
 """
 import numpy as np
 import pytest
