@@ -17,7 +17,7 @@ def run(case, mu0, phi0, label, up, down):
     integ.specifyParameters(minInverseTableSize=9001, useRayTracing=True, useRussianRoulette=True)
     photons = M.new_PhotonStream(mu0, phi0, numberOfPhotons=10 ** 12)
     integ.resetMoments()
-    n = integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, 10 ** 7, 100)
+    n = integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, 10 ** 7, int(os.environ.get("ANALYTIC_BATCHES", "100")))
     st = driver.statistics(driver.unpack_moments(integ.moments(), dom.numX, dom.numY, dom.numZ))
     print("%s n %.0e: up %.6f +- %.6f theory %.6f z %.2f | down %.6f +- %.6f theory %.6f z %.2f | bad %d" % (
         label, n, st["meanFluxUp"], st["meanFluxUp_StdErr"], up, (st["meanFluxUp"] - up) / st["meanFluxUp_StdErr"],
