@@ -645,6 +645,22 @@ def test_oracle_radiance_of_a_forward_scattering_slab_in_the_azimuthal_mean():
     assert np.all(np.abs(mean - theory) < 4.5 * err + 0.003 * theory), (mean, theory, err)
 
 
+def test_the_reference_tallies_in_single_precision_and_large_batches_show_it():
+    """A property of the reference, not of the physics: its tallies are `real` (Integrators/monteCarloRadiativeTransfer.f95:102,
+    `fluxUp(ix, iy) = fluxUp(ix, iy) + photonWeight` :587), so a batch that adds 10^6 weights of a non-conservative medium
+    into ONE column loses 10^-3 to rounding -- the same photons in batches of 10^4 do not.  The oracle keeps the reference's
+    arithmetic (and is therefore compared with theory in small batches); the product tallies in 64-bit fixed point, exactly."""
+    from oracle import oracle as O
+    P = cases.oracle_problem(slab(2.0, 0.9, nz=16), nsteps=1001)
+    n = 1000000
+    one = O.compute_radiative_transfer(P, O.solar_source(0.5, 75.0), O.philox_rng(SEED, 0), n)["meanFluxUp"]
+    parts = float(np.mean([O.compute_radiative_transfer(P, O.solar_source(0.5, 75.0), O.philox_rng(SEED, k * 10000), 10000)["meanFluxUp"]
+                           for k in range(n // 10000)]))
+    up = isotropic_slab(2.0, 0.9, 0.5)[0]
+    assert abs(parts - up) < 4.5 * _sigma(up, n)          # the same photons, small batches: theory
+    assert abs(one - parts) > 4e-4                        # one large batch: rounding, not physics (seen: 1.2e-3)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the product, through the C ABI
 # ---------------------------------------------------------------------------------------------------------------------
@@ -933,3 +949,27 @@ def test_product_thermal_radiance_against_the_formal_solution(tau, omega, temps,
     err = np.sqrt((st["intensity_StdErr"].reshape(-1, len(RADIANCE_MUS)) ** 2).sum(axis=0)) / (nx * nx)
     assert np.all(err < 0.005 * theory)
     assert np.all(np.abs(mean - theory) < 4.5 * err), (mean, theory, err)
+
+
+@pytest.mark.gpu
+def test_product_tallies_do_not_depend_on_the_batch_size():
+    """... where the reference's single-precision tallies do (test_the_reference_tallies_in_single_precision_...): the same
+    2x10^6 photons in one batch and in 200, to the last digit of the float the means are reported in."""
+    import mcbrat3d_amd as M
+    from mcbrat3d_amd import driver
+    from mcbrat3d_amd.integrator import new_RandomNumberSequence
+    case = slab(2.0, 0.9, nz=16)
+    dom = cases.product_domain(case)
+    means = []
+    for ppb, nb in ((2000000, 1), (10000, 200)):
+        integ = M.new_Integrator(dom)
+        integ.specifyParameters(minInverseTableSize=1001, useRayTracing=True, useRussianRoulette=True)
+        photons = M.new_PhotonStream(0.5, 75.0, numberOfPhotons=10 ** 12)
+        integ.resetMoments()
+        assert integ.computeRadiativeTransfer(dom, new_RandomNumberSequence(SEED), photons, ppb, nb) == ppb * nb
+        st = driver.statistics(driver.unpack_moments(integ.moments(), dom.numX, dom.numY, dom.numZ))
+        means.append((float(st["meanFluxUp"]), float(st["meanFluxDown"]), float(st["meanFluxAbsorbed"])))
+        integ.finalize()
+    assert np.allclose(means[0], means[1], rtol=0, atol=2e-7), means
+    up = isotropic_slab(2.0, 0.9, 0.5)[0]
+    assert abs(means[0][0] - up) < 4.5 * _sigma(up, 2000000)
