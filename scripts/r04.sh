@@ -37,7 +37,8 @@ step_poison_all() {  # the rest of the suite under the audit build
 step_base() {  # development timing of the three workloads (not the judged bench)
   local log=$OUT/base_$(ts).log
   { timeout -k 10 200 python scripts/quick_bench.py --case step --thr 16 --reps 5 --counters
-    for lib in ab/libmcbrat_r03.so mcbrat3d_amd/libmcbrat_hip.so; do
+    for lib in ab/libmcbrat_r03.so mcbrat3d_amd/libmcbrat_hip.so; do  # (the round-3 library, where a copy was kept for the A/B: git show 01a0af7, build, copy to ab/)
+      [ -f $ROOT/$lib ] || continue
       echo "== $lib"
       MCBRAT_LIB=$ROOT/$lib MCBRAT_LIB_OLD=1 timeout -k 10 200 python scripts/quick_bench.py --case landsat --ppb 1000000 --batches 100 --thr 20 --reps 3
       MCBRAT_LIB=$ROOT/$lib MCBRAT_LIB_OLD=1 timeout -k 10 200 python scripts/quick_bench.py --case radar --ppb 1000000 --batches 100 --thr 24 --reps 3
